@@ -1,0 +1,110 @@
+"""Seeded synthetic weights and inputs for the GATsSPG matcher.
+
+There is no checkpoint and no dataset in the build environment, so benchmarks and parity
+tests run on random-init weights of the reference architecture and synthetic unit-norm
+descriptors (real SuperPoint descriptors are unit-norm).  Everything here is
+generated with ``numpy.random.RandomState`` so the very same tensors can be rebuilt bit for
+bit on any machine (golden-vector generation in the build container, parity tests on the GPU
+box) without shipping 22 MB of weights.
+
+Parameter names / shapes follow the reference ``state_dict`` exactly
+(src/models/GATsSPG_architectures/GATs_SuperGlue.py:145-177, GATs.py:25-28).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+D = 256
+GATS_LAYERS = (0, 3, 6, 9)
+ATTN_LAYERS = (1, 2, 4, 5, 7, 8, 10, 11)
+
+
+def _conv(rs, out_c, in_c):
+    """PyTorch's default Conv1d init: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias."""
+    bound = 1.0 / np.sqrt(in_c)
+    w = rs.uniform(-bound, bound, size=(out_c, in_c, 1)).astype(np.float32)
+    b = rs.uniform(-bound, bound, size=(out_c,)).astype(np.float32)
+    return w, b
+
+
+def make_state_dict(seed=0, keypoints_encoder=(32, 64, 128)):
+    """Random-init weights with the distributions of the reference constructors
+    (xavier_normal(gain=1.414) for GATs W/a, GATs.py:25-28; Conv1d default elsewhere; the last
+    bias of every MLP zero, GATs_SuperGlue.py:109,136)."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for name, inp in (("kenc_2d", 3), ("kenc_3d", 4)):
+        chans = [inp] + list(keypoints_encoder) + [D]
+        for i in range(1, len(chans)):
+            w, b = _conv(rs, chans[i], chans[i - 1])
+            if i == len(chans) - 1:
+                b[:] = 0
+            sd[f"{name}.encoder.{3 * (i - 1)}.weight"] = w
+            sd[f"{name}.encoder.{3 * (i - 1)}.bias"] = b
+    for i in range(12):
+        p = f"gnn.layers.{i}"
+        if i in GATS_LAYERS:
+            sd[f"{p}.W"] = (rs.standard_normal((D, D)) * 1.414 * np.sqrt(2.0 / (D + D))).astype(np.float32)
+            sd[f"{p}.a"] = (rs.standard_normal((2 * D, 1)) * 1.414 * np.sqrt(2.0 / (2 * D + 1))).astype(np.float32)
+        else:
+            w, b = _conv(rs, D, D)
+            sd[f"{p}.attn.merge.weight"], sd[f"{p}.attn.merge.bias"] = w, b
+            for j in range(3):
+                w, b = _conv(rs, D, D)
+                sd[f"{p}.attn.proj.{j}.weight"], sd[f"{p}.attn.proj.{j}.bias"] = w, b
+            w, b = _conv(rs, 2 * D, 2 * D)
+            sd[f"{p}.mlp.0.weight"], sd[f"{p}.mlp.0.bias"] = w, b
+            w, b = _conv(rs, D, 2 * D)
+            b[:] = 0
+            sd[f"{p}.mlp.3.weight"], sd[f"{p}.mlp.3.bias"] = w, b
+    w, b = _conv(rs, D, D)
+    sd["final_proj.weight"], sd["final_proj.bias"] = w, b
+    sd["bin_score"] = np.array(1.0, dtype=np.float32)
+    return sd
+
+
+def make_passthrough_state_dict(seed=0):
+    """Fixture-B weights: the last MLP conv of every AttentionPropagation layer
+    is zeroed (deltas vanish) and final_proj is the identity, so planted descriptor matches
+    survive the network and the dual-softmax produces confidences near 1."""
+    sd = make_state_dict(seed)
+    for i in ATTN_LAYERS:
+        sd[f"gnn.layers.{i}.mlp.3.weight"][:] = 0
+        sd[f"gnn.layers.{i}.mlp.3.bias"][:] = 0
+    sd["final_proj.weight"] = np.eye(D, dtype=np.float32)[:, :, None].copy()
+    sd["final_proj.bias"][:] = 0
+    return sd
+
+
+def _unit(x, axis):
+    return (x / np.linalg.norm(x, axis=axis, keepdims=True)).astype(np.float32)
+
+
+def make_inputs(b, n1, n2, num_leaf=8, seed=1, planted=False):
+    """Synthetic forward() inputs (keys of GATs_SuperGlue.py:181-189).
+
+    planted=False: independent unit-norm random descriptors (benchmark distribution).
+    planted=True (fixture B): leaves are noisy copies (noise norm ~0.2) of their 3D descriptor and
+    the first n1//2 query descriptors are noisy copies (noise norm ~0.3) of distinct random 3D
+    descriptors, so well-separated ground-truth matches exist.
+    """
+    rs = np.random.RandomState(seed)
+    d3 = _unit(rs.standard_normal((b, D, n2)), 1)
+    if planted:
+        leaves = np.repeat(d3, num_leaf, axis=2) + 0.2 * rs.standard_normal((b, D, n2 * num_leaf)) / np.sqrt(D)
+        d2db = _unit(leaves, 1)
+        dq = _unit(rs.standard_normal((b, D, n1)), 1)
+        k = min(n1 // 2, n2)
+        for bi in range(b):
+            tgt = rs.permutation(n2)[:k]
+            dq[bi, :, :k] = _unit(d3[bi][:, tgt] + 0.3 * rs.standard_normal((D, k)) / np.sqrt(D), 0)
+    else:
+        d2db = _unit(rs.standard_normal((b, D, n2 * num_leaf)), 1)
+        dq = _unit(rs.standard_normal((b, D, n1)), 1)
+    return {
+        "keypoints2d": (rs.rand(b, n1, 2) * 512).astype(np.float32),
+        "keypoints3d": (rs.rand(b, n2, 3) - 0.5).astype(np.float32),
+        "descriptors2d_query": dq,
+        "descriptors3d_db": d3,
+        "descriptors2d_db": d2db,
+    }

@@ -1,0 +1,92 @@
+"""Pin the numpy oracle against the golden vectors produced by the reference module
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import case_inputs, load_golden
+from oracle import gatsspg_oracle as orc
+
+SMALL = ["rand_small", "planted_small", "ragged_leaf3", "two_points", "flags_noself", "flags_wlt",
+         "flags_wlt_add", "flags_noself_wlt", "flags_add"]
+ATOL_CONF = 1e-6  # fp32 re-association noise between numpy and ATen; reference-vs-fp64 floor is 1e-8
+RTOL = 2e-4
+
+
+def _check_pred(pred, g):
+    np.testing.assert_array_equal(pred["matches0"], g["matches0"])
+    np.testing.assert_array_equal(pred["matches1"], g["matches1"])
+    np.testing.assert_allclose(pred["matching_scores0"], g["matching_scores0"], atol=ATOL_CONF, rtol=RTOL)
+    np.testing.assert_allclose(pred["matching_scores1"], g["matching_scores1"], atol=ATOL_CONF, rtol=RTOL)
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_matches_reference_small(name, golden_meta):
+    g = load_golden(name)
+    sd, data, hp = case_inputs(golden_meta["cases"][name])
+    pred, conf, inter = orc.forward(sd, data, hp, return_intermediates=True)
+    assert conf.shape == tuple(g["conf_shape"])
+    if name == "two_points":
+        # InstanceNorm over 2 points is ill-conditioned ((x-m)/sqrt(var+eps) with var ~ (x1-x2)^2/4):
+        # fp32 rounding differences are amplified to ~1e-3; plumbing check only.
+        np.testing.assert_allclose(conf, g["conf"], atol=5e-3)
+        np.testing.assert_array_equal(pred["matches0"], g["matches0"])
+        return
+    np.testing.assert_allclose(conf, g["conf"], atol=ATOL_CONF, rtol=RTOL)
+    np.testing.assert_allclose(inter["mdesc2d"][:, :, ::3], g["mdesc2d_sub"], atol=1e-5)
+    np.testing.assert_allclose(inter["mdesc3d"][:, :, ::5], g["mdesc3d_sub"], atol=1e-5)
+    np.testing.assert_array_equal(inter["batched"]["indices0_raw"], g["indices0_raw"])
+    np.testing.assert_array_equal(inter["batched"]["indices1_raw"], g["indices1_raw"])
+    _check_pred(pred, g)
+    assert pred["matches0"].dtype == np.int64
+
+
+@pytest.mark.parametrize("name", ["rand_small", "flags_wlt_add"])
+def test_oracle_layer_trace(name, golden_meta):
+    """Per-layer: the GATs outputs of the oracle against the reference's forward hooks."""
+    g = load_golden(name)
+    sd, data, hp = case_inputs(golden_meta["cases"][name])
+    _, _, inter = orc.forward(sd, data, hp, return_intermediates=True)
+    keys = sorted(k for k in g if k.startswith("trace_"))
+    gats = [k for k in keys if int(k.split("layer")[1]) % 3 == 0]
+    assert len(gats) == 4 and len(keys) == 4 + 16
+    for k in gats:
+        layer = int(k.split("layer")[1])
+        d3 = inter["trace"][layer][3]  # desc3d after that layer, [b,256,N]
+        np.testing.assert_allclose(np.transpose(d3, (0, 2, 1))[:, :6, :], g[k], atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["rand_mid", "planted_mid"])
+def test_oracle_matches_reference_mid(name, golden_meta):
+    g = load_golden(name)
+    sd, data, hp = case_inputs(golden_meta["cases"][name])
+    pred, conf, inter = orc.forward(sd, data, hp, return_intermediates=True)
+    np.testing.assert_allclose(conf[:, ::7, ::13], g["conf_sub"], atol=ATOL_CONF, rtol=RTOL)
+    np.testing.assert_allclose(conf.max(axis=2), g["conf_rowmax"], atol=ATOL_CONF, rtol=RTOL)
+    np.testing.assert_allclose(conf.max(axis=1), g["conf_colmax"], atol=ATOL_CONF, rtol=RTOL)
+    np.testing.assert_allclose(conf.sum(axis=2, dtype=np.float64), g["conf_rowsum"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_array_equal(inter["batched"]["indices0_raw"], g["indices0_raw"])
+    np.testing.assert_array_equal(inter["batched"]["indices1_raw"], g["indices1_raw"])
+    _check_pred(pred, g)
+    assert int((pred["matches0"] >= 0).sum()) == golden_meta["cases"][name]["valid_matches0"]
+
+
+def test_oracle_keypoint_encoder():
+    from onepose_amd import synthetic
+    g = load_golden("kenc")
+    sd = synthetic.make_state_dict(0)
+    o2 = orc.keypoint_encoder(sd, "kenc_2d", g["kpts2d"], g["scores2d"])
+    o3 = orc.keypoint_encoder(sd, "kenc_3d", g["kpts3d"], g["scores3d"])
+    np.testing.assert_allclose(o2, g["out2d"], atol=3e-5, rtol=1e-4)
+    np.testing.assert_allclose(o3, g["out3d"], atol=3e-5, rtol=1e-4)
+
+
+def test_oracle_empty_input(golden_meta):
+    from onepose_amd import synthetic
+    out = orc.forward(synthetic.make_state_dict(0), synthetic.make_inputs(1, 0, 5, 8, seed=3))
+    meta = golden_meta["empty"]
+    assert isinstance(out, dict) and set(out) == set(meta)
+    assert out["skip_train"] is True
+    for k in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+        assert list(out[k].shape) == meta[k][0]
+        assert str(out[k].dtype) == meta[k][1].replace("torch.", "")
+    assert (out["matches1"] == -1).all()
