@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Benchmark of the GATsSPG matcher hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one GATsSuperGlue.forward-equivalent (descriptors already resident in HBM ->
+pred + conf_matrix in HBM) on BASELINE.json configs[1]: synthetic unit-norm descriptors,
+N_2D=1000, N_3D=7000, d=256, num_leaf=8, batch 1, fp32, random-init weights.  With N>1 every rank
+runs its own K frames (weak scaling, no data-path collective); value = all frames / max-over-ranks time.
+
+The JSON line also carries
+  roofline     : the dominant kernel (mlp0: the folded merge+mlp.0 fp32-MFMA GEMM) timed live with HIP
+                 events recorded on the compute stream around one of its launches in every timed step;
+  cpu_baseline : the numpy oracle (a port of the reference algorithm) timed on this host's cores on a
+                 bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from onepose_amd import GATsSuperGlue, _native, sharding, synthetic  # noqa: E402
+
+N1, N2, NUM_LEAF, D = 1000, 7000, 8, 256
+HP = {"descriptor_dim": 256, "keypoints_encoder": [32, 64, 128], "match_type": "softmax", "scale_factor": 0.07,
+      "match_threshold": 0.2, "include_self": True, "additional": False, "with_linear_transform": False}
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+DOMINANT = "mlp0"
+
+
+def f_alg(n1, n2, L, d=256):
+    """Algorithmic flops per frame, SURVEY.md 8(d)."""
+    return 16 * n2 * d * (L + 1) + 170 * (n1 + n2) * d * d + 2 * n1 * n2 * d
+
+
+def kernel_flops(name, n1, n2):
+    """Useful flops EXECUTED per launch on the real (unpadded) points."""
+    n = n1 + n2
+    return {"mlp0": 2 * 512 * 512 * n,          # [512x512] x [x ; msg]  (merge folded in: algorithmic 10 d^2 n)
+            "qkv_kv": 2 * 768 * 256 * n + 2 * 256 * 64 * n,
+            "mlp3": 2 * 256 * 512 * n,
+            "score_exp": 2 * n1 * n2 * 256}[name]
+
+
+class Runner:
+    """Everything pre-allocated; step() is a single C-ABI call on the current stream."""
+
+    def __init__(self, device, b=1, n1=N1, n2=N2, n_query_frames=4):
+        self.device = device
+        self.b, self.n1, self.n2 = b, n1, n2
+        sd = synthetic.make_state_dict(0)
+        self.model = GATsSuperGlue(HP).eval()
+        self.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        self.model.to(device)
+        data = synthetic.make_inputs(b, n1, n2, NUM_LEAF, seed=1)
+        self.d3 = torch.from_numpy(data["descriptors3d_db"]).to(device)
+        self.d2db = torch.from_numpy(data["descriptors2d_db"]).to(device)
+        rs = np.random.RandomState(7)
+        q = rs.standard_normal((n_query_frames, b, D, n1)).astype(np.float32)
+        q /= np.linalg.norm(q, axis=2, keepdims=True)
+        self.queries = [torch.from_numpy(q[i]).to(device) for i in range(n_query_frames)]
+        eng = self.model.engine
+        self.lib = eng.lib
+        self.packed = eng.packed_weights(device)
+        self.ws = eng.workspace(b, n1, n2, NUM_LEAF, device)
+        self.flags = eng.flags()
+        self.conf = torch.empty(b, n1, n2, device=device)
+        self.m0 = torch.empty(b, n1, device=device, dtype=torch.int64)
+        self.m1 = torch.empty(b, n2, device=device, dtype=torch.int64)
+        self.s0 = torch.empty(b, n1, device=device)
+        self.s1 = torch.empty(b, n2, device=device)
+        self.stream = torch.cuda.current_stream(device)
+
+    def _common(self, i):
+        q = self.queries[i % len(self.queries)]
+        return (self.packed.data_ptr(), q.data_ptr(), self.d3.data_ptr(), self.d2db.data_ptr(), self.b, self.n1, self.n2,
+                NUM_LEAF, self.flags, HP["scale_factor"], HP["match_threshold"], self.conf.data_ptr(), self.m0.data_ptr(),
+                self.m1.data_ptr(), self.s0.data_ptr(), self.s1.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                self.stream.cuda_stream)
+
+    def step(self, i):
+        _native.check(self.lib.gatsspg_forward(*self._common(i)), "gatsspg_forward")
+
+    def step_profiled(self, i, kernel, ev0, ev1, occurrence=0):
+        _native.check(self.lib.gatsspg_forward_profiled(*self._common(i), _native.KERNEL_IDS[kernel], occurrence,
+                                                        ev0.cuda_event, ev1.cuda_event), "gatsspg_forward_profiled")
+
+
+def cpu_baseline(max_seconds=30.0):
+    """The oracle (numpy port of the reference algorithm) on this host, headline shape, batch 1."""
+    from oracle import gatsspg_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:  # noqa: BLE001
+        threads = os.cpu_count()
+    sd = synthetic.make_state_dict(0)
+    data = synthetic.make_inputs(1, N1, N2, NUM_LEAF, seed=1)
+    t0 = time.perf_counter()
+    orc.forward(sd, data, HP)  # warm-up (also bounds the sample)
+    warm = time.perf_counter() - t0
+    n = max(1, min(3, int(max_seconds / max(warm, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        orc.forward(sd, data, HP)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} frame(s) after 1 warm-up, N_2D={N1} N_3D={N2} num_leaf={NUM_LEAF} batch 1 fp32, numpy oracle "
+                      f"(literal reference algorithm incl. the h@W GEMMs), {dt * 1e3:.0f} ms/frame"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", default=DOMINANT, choices=["mlp0", "qkv_kv", "mlp3", "score_exp"])
+    args = ap.parse_args()
+
+    rank, local_rank, world = sharding.init_process_group()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(device)
+
+    runner = Runner(device)
+    K, W = args.steps, args.warmup
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    for e0, e1 in events:  # create the underlying hipEvent_t handles
+        e0.record(runner.stream)
+        e1.record(runner.stream)
+    for i in range(W):
+        runner.step(i)
+    torch.cuda.synchronize(device)
+    sharding.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(K):
+        runner.step_profiled(i, args.kernel, events[i][0], events[i][1])
+    torch.cuda.synchronize(device)
+    sharding.barrier()
+    elapsed = time.perf_counter() - t0
+
+    per_rank = sharding.gather_metrics([K * runner.b, elapsed], device=device)  # the one (RCCL) collective
+    value, seconds = sharding.aggregate_throughput(per_rank.cpu())
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+
+    if rank == 0:
+        fl = kernel_flops(args.kernel, N1, N2)
+        achieved = fl / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "query_frames_per_sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": round(seconds / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic unit-norm desc_2d/desc_3d, N_2D=1000 N_3D=7000 d=256 "
+                                   "num_leaf=8, batch=1 per step, fp32, random-init GATsSPG weights (12 GNN layers)",
+                       "n_2d": N1, "n_3d": N2, "num_leaf": NUM_LEAF, "batch": runner.b, "frames_per_gpu": K,
+                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
+                       "algorithmic_gflop_per_frame": round(f_alg(N1, N2, NUM_LEAF) / 1e9, 2),
+                       "end_to_end_f32_mfma_frac": round(f_alg(N1, N2, NUM_LEAF) * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "roofline": {"bound": "mfma", "kernel": args.kernel + "_kernel", "achieved": round(achieved, 2),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": None, "kernel_ms": round(kern_ms, 5), "flops_per_launch": fl,
+                         "how": f"hipEvent pair around launch #0 of {args.kernel}_kernel in each of the {K} timed steps"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+/*
+ * gatsspg.h -- C ABI of libgatsspg_hip.so: the MI355X (gfx950) implementation of the OnePose
+ * GATsSPG 2D-3D matcher forward pass.
+ *
+ * The reference has no native/FFI boundary for this path: its boundary is the Python
+ * nn.Module `GATsSuperGlue` (reference src/models/GATsSPG_architectures/GATs_SuperGlue.py:143-241,
+ * called from inference.py:146 through src/models/GATsSPG_lightning_model.py:36-37).  The entry
+ * points below are what a ctypes binding of that module binds; each one
+ * names the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP), fp32 unless stated, 16-byte aligned, contiguous;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing here
+ *     allocates, synchronises, or keeps global mutable state (graph-capture safe);
+ *   - return value 0 = OK, non-zero = error; gatsspg_last_error() returns a thread-local
+ *     message for the last failing call of the calling thread;
+ *   - the only supported descriptor dimension is 256 with 4 heads (hard-coded in the reference
+ *     at GATs_SuperGlue.py:35-36,43).
+ *
+ * Tensor shapes use the reference's names: b batch, n1 = N_2D query keypoints, n2 = N_3D points,
+ * num_leaf = per-view 2D descriptors ("leaves") per 3D point.
+ */
+#ifndef GATSSPG_H
+#define GATSSPG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GATSSPG_D 256
+#define GATSSPG_HEADS 4
+#define GATSSPG_NUM_ATTN_LAYERS 8 /* 'self','cross' x4  (GATs_SuperGlue.py:162) */
+#define GATSSPG_NUM_GATS_LAYERS 4 /* 'GATs' x4 */
+
+/* GraphAttentionLayer flags (GATs.py:14-16, hparams include_self/additional/with_linear_transform) */
+#define GATSSPG_FLAG_INCLUDE_SELF 1
+#define GATSSPG_FLAG_ADDITIONAL 2
+#define GATSSPG_FLAG_WITH_LINEAR_TRANSFORM 4
+/* layer kinds for gatsspg_attn_layer (GATs_SuperGlue.py:55-64) */
+#define GATSSPG_LAYER_SELF 0
+#define GATSSPG_LAYER_CROSS 1
+
+/* Raw parameter pointers, exactly the tensors of the reference state_dict that forward() uses
+ * (SURVEY.md 8(b)); index [i] runs over the 4 GATs layers (gnn.layers.{0,3,6,9}) or the 8
+ * AttentionPropagation layers (gnn.layers.{1,2,4,5,7,8,10,11}). */
+typedef struct gatsspg_raw_weights {
+    const float* gats_W[GATSSPG_NUM_GATS_LAYERS];       /* [256,256]  h @ W           (GATs.py:25,40) */
+    const float* gats_a[GATSSPG_NUM_GATS_LAYERS];       /* [512,1]                    (GATs.py:27)    */
+    const float* proj_w[GATSSPG_NUM_ATTN_LAYERS][3];    /* attn.proj.{0,1,2}.weight [256,256,1] (:91)  */
+    const float* proj_b[GATSSPG_NUM_ATTN_LAYERS][3];    /* attn.proj.{0,1,2}.bias   [256]              */
+    const float* merge_w[GATSSPG_NUM_ATTN_LAYERS];      /* attn.merge.weight [256,256,1]        (:90)  */
+    const float* merge_b[GATSSPG_NUM_ATTN_LAYERS];      /* attn.merge.bias   [256]                     */
+    const float* mlp0_w[GATSSPG_NUM_ATTN_LAYERS];       /* mlp.0.weight [512,512,1]             (:108) */
+    const float* mlp0_b[GATSSPG_NUM_ATTN_LAYERS];       /* mlp.0.bias   [512]                          */
+    const float* mlp3_w[GATSSPG_NUM_ATTN_LAYERS];       /* mlp.3.weight [256,512,1]                    */
+    const float* mlp3_b[GATSSPG_NUM_ATTN_LAYERS];       /* mlp.3.bias   [256]                          */
+    const float* final_w;                               /* final_proj.weight [256,256,1]        (:170) */
+    const float* final_b;                               /* final_proj.bias   [256]                     */
+} gatsspg_raw_weights;
+
+/* KeypointEncoder parameters (GATs_SuperGlue.py:131-140; built, never called by forward). */
+typedef struct gatsspg_kenc_weights {
+    const float* w[4]; /* encoder.{0,3,6,9}.weight [c_out, c_in, 1], c = inp,32,64,128,256 */
+    const float* b[4]; /* encoder.{0,3,6,9}.bias */
+    int inp_dim;       /* 3 (kenc_2d) or 4 (kenc_3d) */
+} gatsspg_kenc_weights;
+
+int gatsspg_version(void);
+const char* gatsspg_last_error(void);
+
+/* Size in bytes of the packed-weights blob / of the workspace for a given problem. */
+size_t gatsspg_packed_weights_bytes(void);
+size_t gatsspg_workspace_bytes(int b, int n1, int n2, int num_leaf);
+
+/* One-time weight preparation (replaces nothing in the reference; it is what
+ * load_state_dict + .cuda() is to it).  Re-orders the q/k/v projection rows head-major, folds
+ * merge into mlp.0 (W0[:,256:] @ Wm), folds W @ a[:256], W @ a[256:] of each GATs layer. */
+int gatsspg_pack_weights(const gatsspg_raw_weights* raw, float* packed, void* stream);
+
+/* Whole forward: GATsSuperGlue.forward, GATs_SuperGlue.py:179-241, for all b samples.
+ *   desc2d_query [b,256,n1]  desc3d_db [b,256,n2]  desc2d_db [b,256,n2*num_leaf]
+ *   conf [b,n1,n2]; matches0 [b,n1] int64; matches1 [b,n2] int64; mscores0 [b,n1]; mscores1 [b,n2]
+ * n1 >= 2 and n2 >= 2 (the reference raises for a single point, and returns early for 0). */
+int gatsspg_forward(const float* packed, const float* desc2d_query, const float* desc3d_db,
+                    const float* desc2d_db, int b, int n1, int n2, int num_leaf, int flags,
+                    float scale_factor, float match_threshold, float* conf, int64_t* matches0,
+                    int64_t* matches1, float* mscores0, float* mscores1, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* Same forward, with a HIP-event bracket (hipEvent_t, created by the caller, recorded on `stream`)
+ * around the `occurrence`-th launch of one kernel -- how bench.py times the dominant kernel live.
+ * kernel_id: 0 load_state, 1 gats, 2 qkv_kv, 3 kv_final, 4 attn_apply, 5 mlp0, 6 stat_final, 7 mlp3,
+ * 8 final_proj_norm, 9 score_exp, 10 softmax_sums, 11 conf_finalize, 12 match_reduce, 13 match_tail. */
+int gatsspg_forward_profiled(const float* packed, const float* desc2d_query, const float* desc3d_db,
+                             const float* desc2d_db, int b, int n1, int n2, int num_leaf, int flags,
+                             float scale_factor, float match_threshold, float* conf, int64_t* matches0,
+                             int64_t* matches1, float* mscores0, float* mscores1, void* ws, size_t ws_bytes,
+                             void* stream, int kernel_id, int occurrence, void* ev_start, void* ev_stop);
+
+/* ---- per-stage entry points (the stages gatsspg_forward is made of; used by the parity
+ *      tests to check each kernel against the oracle).  They operate on the workspace state. */
+
+/* loads desc2d_query / desc3d_db into the padded channel-major state (GATs_SuperGlue.py:192-193) */
+int gatsspg_load_state(const float* desc2d_query, const float* desc3d_db, int b, int n1, int n2,
+                       int num_leaf, void* ws, size_t ws_bytes, void* stream);
+/* copies the current state (which=0) or the normalised final descriptors (which=1) out of the
+ * workspace as [b,256,n1] and [b,256,n2] */
+int gatsspg_store_state(int which, float* out2d, float* out3d, int b, int n1, int n2, int num_leaf,
+                        void* ws, size_t ws_bytes, void* stream);
+/* GraphAttentionLayer.forward (GATs.py:35-88) on the state's 3D side; layer = 0..3 */
+int gatsspg_gats_layer(const float* packed, int layer, const float* desc2d_db, int b, int n1, int n2,
+                       int num_leaf, int flags, void* ws, size_t ws_bytes, void* stream);
+/* one 'self' or 'cross' layer, both sides: AttentionalGNN.forward branch GATs_SuperGlue.py:55-64
+ * = 2x AttentionPropagation.forward (:111-113) + residual; layer = 0..7 */
+int gatsspg_attn_layer(const float* packed, int layer, int kind, int b, int n1, int n2, int num_leaf,
+                       void* ws, size_t ws_bytes, void* stream);
+/* final_proj + F.normalize (GATs_SuperGlue.py:209-213) */
+int gatsspg_final_proj_norm(const float* packed, int b, int n1, int n2, int num_leaf, void* ws,
+                            size_t ws_bytes, void* stream);
+/* score einsum / scale, dual softmax, mutual-NN matching (GATs_SuperGlue.py:217-237) */
+int gatsspg_score_dual_softmax_match(int b, int n1, int n2, int num_leaf, float scale_factor,
+                                     float match_threshold, float* conf, int64_t* matches0,
+                                     int64_t* matches1, float* mscores0, float* mscores1, void* ws,
+                                     size_t ws_bytes, void* stream);
+
+/* KeypointEncoder.forward (GATs_SuperGlue.py:138-140): kpts [b,n,inp_dim-1], scores [b,n]
+ * -> out [b,256,n].  scratch: at least gatsspg_kenc_scratch_bytes(b,n) bytes. */
+size_t gatsspg_kenc_scratch_bytes(int b, int n);
+int gatsspg_keypoint_encoder(const gatsspg_kenc_weights* w, const float* kpts, const float* scores,
+                             int b, int n, float* out, void* scratch, size_t scratch_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GATSSPG_H */

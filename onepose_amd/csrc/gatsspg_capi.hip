@@ -1,0 +1,222 @@
+// C ABI of libgatsspg_hip.so (declared in include/gatsspg.h).  Thin: argument checks, workspace
+// carve-up, kernel enqueue on the caller's stream.  No allocation, no synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gatsspg.h"
+#include "gatsspg_launch.h"
+
+using namespace gatsspg;
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+int check_dims(int b, int n1, int n2, int num_leaf) {
+    if (b < 1) return fail("batch must be >= 1 (got %d)", b);
+    // the reference returns early for an empty side (GATs_SuperGlue.py:195) and InstanceNorm1d raises for
+    // a single point (:126); both are handled by the host-side module, never enqueued.
+    if (n1 < 2 || n2 < 2) return fail("n1 and n2 must be >= 2 (got n1=%d n2=%d)", n1, n2);
+    if (num_leaf < 1 || num_leaf > 64) return fail("num_leaf must be in [1, 64] (got %d)", num_leaf);
+    const long long ld = (long long)b * (round_up(n1, CP) + round_up(n2, CP));
+    if (ld * 512 >= (1ll << 31)) return fail("problem too large: b*(n1p+n2p) = %lld columns", ld);
+    if ((long long)n1 * n2 >= (1ll << 31)) return fail("n1*n2 too large");
+    return 0;
+}
+
+int check_ws(const void* ws, size_t ws_bytes, int b, int n1, int n2, int num_leaf, Workspace& w) {
+    if (int e = check_dims(b, n1, n2, num_leaf)) return e;
+    if (!ws) return fail("workspace pointer is null");
+    if (reinterpret_cast<uintptr_t>(ws) & 15) return fail("workspace must be 16-byte aligned");
+    w = carve_workspace(const_cast<void*>(ws), b, n1, n2);
+    if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu bytes", ws_bytes, w.bytes);
+    return 0;
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+const float* attn_w(const float* packed, int layer) { return packed + PW_ATTN + (size_t)layer * AttnW::SIZE; }
+const float* gats_w(const float* packed, int layer) { return packed + PW_GATS + (size_t)layer * GatsW::SIZE; }
+
+void enqueue_gats(const float* packed, int layer, const float* desc2d_db, int num_leaf, int flags, const Workspace& w,
+                  hipStream_t s, ProfileHook* hk = nullptr) {
+    const float* g = gats_w(packed, layer);
+    if (flags & GATSSPG_FLAG_WITH_LINEAR_TRANSFORM) {
+        // pre-activation aggregate -> MSG (free between attention layers), then elu(W^T pre (+h))
+        launch_gats(g + GatsW::U1, g + GatsW::U2, desc2d_db, num_leaf, flags, w.MSG, w, s, hk);
+        const int add_h = (flags & GATSSPG_FLAG_INCLUDE_SELF) && (flags & GATSSPG_FLAG_ADDITIONAL);
+        launch_gats_wlt(g + GatsW::W, w.MSG, w, add_h, s, hk);
+    } else {
+        launch_gats(g + GatsW::U1, g + GatsW::U2, desc2d_db, num_leaf, flags, w.Z, w, s, hk);
+    }
+}
+
+void enqueue_attn(const float* packed, int layer, int kind, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr) {
+    const float* a = attn_w(packed, layer);
+    launch_qkv_kv(a + AttnW::WQKV, a + AttnW::BQKV, w, s, hk);
+    launch_attn_apply(w, kind == GATSSPG_LAYER_CROSS, s, hk);
+    launch_mlp(a + AttnW::W0, a + AttnW::B0, a + AttnW::W3, a + AttnW::B3, w, s, hk);
+}
+
+int forward_impl(const float* packed, const float* desc2d_query, const float* desc3d_db, const float* desc2d_db, int b,
+                 int n1, int n2, int num_leaf, int flags, float scale_factor, float match_threshold, float* conf,
+                 int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, void* ws, size_t ws_bytes,
+                 void* stream, ProfileHook* hk) {
+    Workspace w;
+    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
+    if (!packed || !desc2d_query || !desc3d_db || !desc2d_db) return fail("null input pointer");
+    if (!conf || !matches0 || !matches1 || !mscores0 || !mscores1) return fail("null output pointer");
+    if (!(scale_factor > 0.f)) return fail("scale_factor must be positive");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    launch_load_state(desc2d_query, desc3d_db, w, s, hk);
+    for (int t = 0; t < 4; ++t) {  // ['GATs', 'self', 'cross'] * 4, GATs_SuperGlue.py:162
+        enqueue_gats(packed, t, desc2d_db, num_leaf, flags, w, s, hk);
+        enqueue_attn(packed, 2 * t, GATSSPG_LAYER_SELF, w, s, hk);
+        enqueue_attn(packed, 2 * t + 1, GATSSPG_LAYER_CROSS, w, s, hk);
+    }
+    launch_final_proj_norm(packed + PW_FINAL_W, packed + PW_FINAL_B, w, s, hk);
+    launch_score_exp(w, conf, scale_factor, s, hk);
+    launch_dual_softmax_match(w, conf, match_threshold, matches0, matches1, mscores0, mscores1, s, hk);
+    return check_launch("forward");
+}
+}  // namespace
+
+extern "C" {
+
+int gatsspg_version(void) { return 100; }
+const char* gatsspg_last_error(void) { return g_err; }
+
+size_t gatsspg_packed_weights_bytes(void) { return sizeof(float) * PW_TOTAL; }
+
+size_t gatsspg_workspace_bytes(int b, int n1, int n2, int num_leaf) {
+    if (check_dims(b, n1, n2, num_leaf)) return 0;
+    return carve_workspace(nullptr, b, n1, n2).bytes;
+}
+
+int gatsspg_pack_weights(const gatsspg_raw_weights* raw, float* packed, void* stream) {
+    if (!raw || !packed) return fail("null argument");
+    const void* const* p = reinterpret_cast<const void* const*>(raw);
+    for (size_t i = 0; i < sizeof(gatsspg_raw_weights) / sizeof(void*); ++i)
+        if (!p[i]) return fail("raw weight pointer #%zu is null", i);
+    launch_pack_weights(raw, packed, static_cast<hipStream_t>(stream));
+    return check_launch("pack_weights");
+}
+
+int gatsspg_load_state(const float* dq, const float* d3, int b, int n1, int n2, int num_leaf, void* ws, size_t ws_bytes,
+                       void* stream) {
+    Workspace w;
+    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
+    if (!dq || !d3) return fail("null descriptor pointer");
+    launch_load_state(dq, d3, w, static_cast<hipStream_t>(stream));
+    return check_launch("load_state");
+}
+
+int gatsspg_store_state(int which, float* out2d, float* out3d, int b, int n1, int n2, int num_leaf, void* ws,
+                        size_t ws_bytes, void* stream) {
+    Workspace w;
+    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
+    if (!out2d || !out3d) return fail("null output pointer");
+    if (which != 0 && which != 1) return fail("which must be 0 (state) or 1 (normalised final descriptors)");
+    launch_store_state(which == 0 ? w.Z : w.MD, out2d, out3d, w, static_cast<hipStream_t>(stream));
+    return check_launch("store_state");
+}
+
+int gatsspg_gats_layer(const float* packed, int layer, const float* desc2d_db, int b, int n1, int n2, int num_leaf,
+                       int flags, void* ws, size_t ws_bytes, void* stream) {
+    Workspace w;
+    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
+    if (!packed || !desc2d_db) return fail("null argument");
+    if (layer < 0 || layer >= GATSSPG_NUM_GATS_LAYERS) return fail("GATs layer index %d out of range", layer);
+    enqueue_gats(packed, layer, desc2d_db, num_leaf, flags, w, static_cast<hipStream_t>(stream));
+    return check_launch("gats_layer");
+}
+
+int gatsspg_attn_layer(const float* packed, int layer, int kind, int b, int n1, int n2, int num_leaf, void* ws,
+                       size_t ws_bytes, void* stream) {
+    Workspace w;
+    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
+    if (!packed) return fail("null argument");
+    if (layer < 0 || layer >= GATSSPG_NUM_ATTN_LAYERS) return fail("attention layer index %d out of range", layer);
+    if (kind != GATSSPG_LAYER_SELF && kind != GATSSPG_LAYER_CROSS) return fail("kind must be SELF or CROSS");
+    enqueue_attn(packed, layer, kind, w, static_cast<hipStream_t>(stream));
+    return check_launch("attn_layer");
+}
+
+int gatsspg_final_proj_norm(const float* packed, int b, int n1, int n2, int num_leaf, void* ws, size_t ws_bytes,
+                            void* stream) {
+    Workspace w;
+    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
+    if (!packed) return fail("null argument");
+    launch_final_proj_norm(packed + PW_FINAL_W, packed + PW_FINAL_B, w, static_cast<hipStream_t>(stream));
+    return check_launch("final_proj_norm");
+}
+
+int gatsspg_score_dual_softmax_match(int b, int n1, int n2, int num_leaf, float scale_factor, float match_threshold,
+                                     float* conf, int64_t* matches0, int64_t* matches1, float* mscores0,
+                                     float* mscores1, void* ws, size_t ws_bytes, void* stream) {
+    Workspace w;
+    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
+    if (!conf || !matches0 || !matches1 || !mscores0 || !mscores1) return fail("null output pointer");
+    if (!(scale_factor > 0.f)) return fail("scale_factor must be positive");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    launch_score_exp(w, conf, scale_factor, s);
+    launch_dual_softmax_match(w, conf, match_threshold, matches0, matches1, mscores0, mscores1, s);
+    return check_launch("score_dual_softmax_match");
+}
+
+int gatsspg_forward(const float* packed, const float* desc2d_query, const float* desc3d_db, const float* desc2d_db, int b,
+                    int n1, int n2, int num_leaf, int flags, float scale_factor, float match_threshold, float* conf,
+                    int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, void* ws, size_t ws_bytes,
+                    void* stream) {
+    return forward_impl(packed, desc2d_query, desc3d_db, desc2d_db, b, n1, n2, num_leaf, flags, scale_factor,
+                        match_threshold, conf, matches0, matches1, mscores0, mscores1, ws, ws_bytes, stream, nullptr);
+}
+
+int gatsspg_forward_profiled(const float* packed, const float* desc2d_query, const float* desc3d_db,
+                             const float* desc2d_db, int b, int n1, int n2, int num_leaf, int flags, float scale_factor,
+                             float match_threshold, float* conf, int64_t* matches0, int64_t* matches1, float* mscores0,
+                             float* mscores1, void* ws, size_t ws_bytes, void* stream, int kernel_id, int occurrence,
+                             void* ev_start, void* ev_stop) {
+    if (kernel_id < 0 || kernel_id >= KID_COUNT) return fail("kernel_id %d out of range", kernel_id);
+    if (!ev_start || !ev_stop) return fail("null event");
+    ProfileHook hk;
+    memset(&hk, 0, sizeof(hk));
+    hk.kernel_id = kernel_id;
+    hk.occurrence = occurrence;
+    hk.start = static_cast<hipEvent_t>(ev_start);
+    hk.stop = static_cast<hipEvent_t>(ev_stop);
+    if (int e = forward_impl(packed, desc2d_query, desc3d_db, desc2d_db, b, n1, n2, num_leaf, flags, scale_factor,
+                             match_threshold, conf, matches0, matches1, mscores0, mscores1, ws, ws_bytes, stream, &hk))
+        return e;
+    if (hk.seen[kernel_id] <= occurrence) return fail("kernel %d was launched %d times, occurrence %d never ran", kernel_id, hk.seen[kernel_id], occurrence);
+    return 0;
+}
+
+size_t gatsspg_kenc_scratch_bytes(int b, int n) { return (b < 1 || n < 1) ? 0 : kenc_scratch_bytes(b, n); }
+
+int gatsspg_keypoint_encoder(const gatsspg_kenc_weights* kw, const float* kpts, const float* scores, int b, int n,
+                             float* out, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!kw || !kpts || !scores || !out || !scratch) return fail("null argument");
+    if (b < 1 || n < 2) return fail("keypoint encoder needs b >= 1 and n >= 2 (InstanceNorm1d)");
+    if (kw->inp_dim != 3 && kw->inp_dim != 4) return fail("inp_dim must be 3 or 4");
+    for (int i = 0; i < 4; ++i)
+        if (!kw->w[i] || !kw->b[i]) return fail("null encoder weight");
+    if (scratch_bytes < kenc_scratch_bytes(b, n)) return fail("scratch too small");
+    launch_kenc(kw->w, kw->b, kw->inp_dim, kpts, scores, b, n, out, scratch, static_cast<hipStream_t>(stream));
+    return check_launch("keypoint_encoder");
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// Shared host/device definitions: the column layout of the activation state in HBM, the
+// workspace carve-up and the packed-weights blob.  See DESIGN.md "Data layout in HBM".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace gatsspg {
+
+constexpr int D = 256;    // descriptor_dim (hard-coded by the reference GNN, GATs_SuperGlue.py:35-36)
+constexpr int H = 4;      // heads (GATs_SuperGlue.py:43)
+constexpr int DH = 64;    // channels per head
+constexpr int CP = 128;   // column padding granule: every (frame, side) segment starts on a multiple of CP
+constexpr int BK = 32;    // K tile of every MFMA GEMM
+constexpr int KVP = DH * DH + DH;  // one KV partial: 64x64 KV matrix [q][d] + 64 ksum
+
+// tile widths baked into the partial-sum buffers
+constexpr int QKV_BN = 64;    // column tile of the QKV+KV-partial kernel (one KV partial per tile)
+constexpr int MLP0_BN = 64;   // column tile of the mlp.0 kernel (one InstanceNorm partial per tile)
+constexpr int SC_BM = 128;    // score kernel row tile (over n1)
+constexpr int SC_BN = 64;     // score kernel column tile (over n2)
+constexpr int CF_ROWS = 16;   // conf-finalize strip height
+constexpr int CF_COLS = 1024; // conf-finalize chunk width
+
+// Activation state: channel-major [channels][ld] fp32; frame f owns columns [f*np, (f+1)*np):
+// its N_2D query points at [0, n1) of that range (padded to n1p), its N_3D points at
+// [n1p, n1p + n2) (padded to n2p).  A "segment" is one (frame, side) pair: seg = 2*f + side.
+struct ColLayout {
+    int b, n1, n2, n1p, n2p, np, ld;
+};
+
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+__host__ __device__ inline ColLayout make_layout(int b, int n1, int n2) {
+    ColLayout L;
+    L.b = b; L.n1 = n1; L.n2 = n2;
+    L.n1p = round_up(n1, CP); L.n2p = round_up(n2, CP);
+    L.np = L.n1p + L.n2p; L.ld = b * L.np;
+    return L;
+}
+
+struct TileSeg {
+    int frame, side, seg, seg_start, valid;  // valid = number of real (non-pad) columns in the tile
+};
+
+__host__ __device__ inline TileSeg tile_seg(const ColLayout& L, int c0, int bn) {
+    TileSeg t;
+    t.frame = c0 / L.np;
+    int r = c0 - t.frame * L.np;
+    t.side = r >= L.n1p ? 1 : 0;
+    t.seg = t.frame * 2 + t.side;
+    t.seg_start = t.frame * L.np + (t.side ? L.n1p : 0);
+    int v = t.seg_start + (t.side ? L.n2 : L.n1) - c0;
+    t.valid = v < 0 ? 0 : (v > bn ? bn : v);
+    return t;
+}
+
+// ---- packed weights blob (floats) -------------------------------------------------------------
+struct AttnW {  // offsets inside one attention layer block
+    static constexpr size_t WQKV = 0;                          // [768][256] rows: Q head-major, then per head K_h(64) V_h(64)
+    static constexpr size_t BQKV = WQKV + 768 * 256;           // [768]
+    static constexpr size_t W0 = BQKV + 768;                   // [512][512]: [:, :256] = mlp.0 x-half, [:, 256:] = W0b @ Wm (head-major cols)
+    static constexpr size_t B0 = W0 + 512 * 512;               // [512] = b0 + W0b @ bm
+    static constexpr size_t W3 = B0 + 512;                     // [256][512]
+    static constexpr size_t B3 = W3 + 256 * 512;               // [256]
+    static constexpr size_t SIZE = B3 + 256;
+};
+struct GatsW {
+    static constexpr size_t U1 = 0;              // [256] = W @ a[:256]   (leaf logit vector)
+    static constexpr size_t U2 = 256;            // [256] = W @ a[256:]   (3D-point logit vector)
+    static constexpr size_t W = 512;             // [256][256] raw W (only used with_linear_transform)
+    static constexpr size_t SIZE = 512 + 256 * 256;
+};
+constexpr size_t PW_ATTN = 0;
+constexpr size_t PW_GATS = PW_ATTN + 8 * AttnW::SIZE;
+constexpr size_t PW_FINAL_W = PW_GATS + 4 * GatsW::SIZE;
+constexpr size_t PW_FINAL_B = PW_FINAL_W + 256 * 256;
+constexpr size_t PW_TOTAL = PW_FINAL_B + 256;
+
+// ---- workspace carve-up ---------------------------------------------------------------------------
+struct Workspace {
+    ColLayout L;
+    int nt64;          // ld / 64 column tiles
+    int nseg;          // 2*b
+    int sc_nct, sc_nrt;   // score kernel tiles per frame (n2p/SC_BN, n1p/SC_BM)
+    int cf_nst, cf_nch;   // conf-finalize strips / chunks per frame
+    float *Z, *Q, *MSG, *U, *MD;     // MD aliases Q (Q is dead after the GNN); T aliases MSG
+    float *kvpart, *kvfin, *statpart, *stats;
+    float *rowpart, *colpart, *rs, *cs;
+    float *rmax_v, *cmax_v, *max0;
+    int *rmax_i, *cmax_i, *idx0, *idx1;
+    size_t bytes;
+};
+
+inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+inline Workspace carve_workspace(void* base, int b, int n1, int n2) {
+    Workspace w;
+    w.L = make_layout(b, n1, n2);
+    const ColLayout& L = w.L;
+    w.nt64 = L.ld / 64;
+    w.nseg = 2 * b;
+    w.sc_nct = L.n2p / SC_BN;
+    w.sc_nrt = L.n1p / SC_BM;
+    w.cf_nst = (n1 + CF_ROWS - 1) / CF_ROWS;
+    w.cf_nch = (n2 + CF_COLS - 1) / CF_COLS;
+    char* p = static_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t nbytes) { char* r = p ? p + off : nullptr; off += align_up(nbytes); return r; };
+    const size_t ld = L.ld;
+    w.Z = (float*)take(sizeof(float) * D * ld);
+    w.Q = (float*)take(sizeof(float) * D * ld);
+    w.MSG = (float*)take(sizeof(float) * D * ld);
+    w.U = (float*)take(sizeof(float) * 2 * D * ld);
+    w.MD = w.Q;
+    w.kvpart = (float*)take(sizeof(float) * (size_t)w.nt64 * H * KVP);
+    w.kvfin = (float*)take(sizeof(float) * (size_t)w.nseg * H * KVP);
+    w.statpart = (float*)take(sizeof(float) * (size_t)w.nt64 * 2 * 512);
+    w.stats = (float*)take(sizeof(float) * (size_t)w.nseg * 2 * 512);
+    w.rowpart = (float*)take(sizeof(float) * (size_t)b * w.sc_nct * L.n1p);
+    w.colpart = (float*)take(sizeof(float) * (size_t)b * w.sc_nrt * L.n2p);
+    w.rs = (float*)take(sizeof(float) * (size_t)b * L.n1p);
+    w.cs = (float*)take(sizeof(float) * (size_t)b * L.n2p);
+    w.rmax_v = (float*)take(sizeof(float) * (size_t)b * w.cf_nch * L.n1p);
+    w.rmax_i = (int*)take(sizeof(int) * (size_t)b * w.cf_nch * L.n1p);
+    w.cmax_v = (float*)take(sizeof(float) * (size_t)b * w.cf_nst * L.n2p);
+    w.cmax_i = (int*)take(sizeof(int) * (size_t)b * w.cf_nst * L.n2p);
+    w.max0 = (float*)take(sizeof(float) * (size_t)b * L.n1p);
+    w.idx0 = (int*)take(sizeof(int) * (size_t)b * L.n1p);
+    w.idx1 = (int*)take(sizeof(int) * (size_t)b * L.n2p);
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace gatsspg

@@ -1,0 +1,472 @@
+// MFMA kernels of the GATsSPG forward: everything that is a per-point 1x1-convolution GEMM, the
+// linear-attention KV reduction / apply, and the N_2D x N_3D score contraction.
+// Reference maths: GATs_SuperGlue.py:69-128 (linear_attention, MultiHeadedAttention,
+// AttentionPropagation, MLP) and :209-218 (final_proj, normalize, score einsum, exp of the softmax).
+#include "gemm_f32_mfma.h"
+#include "gatsspg_launch.h"
+
+namespace gatsspg {
+
+// =====================================================================================================
+// K1  QKV projection fused with the linear-attention KV / ksum partial reduction.
+//     rows 0..255  : Q = elu(Wq x + bq) + 1  (head-major), written to Qbuf
+//     rows 256..767: per head h a 128-row tile [K_h ; V_h]; K = elu(.)+1, V raw.  K and V are
+//                    never written to HBM: the tile goes to LDS and a second MFMA pass produces
+//                    this column tile's partial  KV_h[q][d] = sum_m V[q][m] K[d][m],  ksum_h[d].
+//     (GATs_SuperGlue.py:96-99 projections, :71-72 feature map, :77-78 KV and key.sum)
+// =====================================================================================================
+using QkvTile = GemmTile<128, QKV_BN, 2, 2, false>;
+
+__global__ __launch_bounds__(256) void qkv_kv_kernel(const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
+                                                     const float* __restrict__ Z, float* __restrict__ Qbuf,
+                                                     float* __restrict__ kvpart, ColLayout L) {
+    using T = QkvTile;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int rt, ct;
+    const int NT = L.ld / T::BN;
+    if (!xcd_tile_map(6, NT, rt, ct)) return;
+    const int c0 = ct * T::BN;
+    const int ld = L.ld;
+    const float* A = Wqkv + (size_t)rt * 128 * D;
+    f32x16 acc[T::TM][T::TN];
+    zero_acc(acc);
+    gemm_mainloop<T>(
+        acc, smem, D / BK,
+        [&](int kt, int r, int c) { return *reinterpret_cast<const float4*>(A + (size_t)r * D + kt * BK + c); },
+        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(Z + (size_t)(kt * BK + k) * ld + c0 + c); });
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    if (rt < 2) {
+#pragma unroll
+        for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * 128 + wm * 64 + tm * 32 + mfma_row(r, half);
+                const float v = acc[tm][0][r] + bqkv[row];
+                Qbuf[(size_t)row * ld + c0 + wn * 32 + l31] = elu1(v) + 1.f;
+            }
+        return;
+    }
+    // ---- K_h / V_h tile -> LDS -> KV partial ----
+    const int h = rt - 2;
+    const TileSeg ts = tile_seg(L, c0, T::BN);
+    constexpr int TS = T::BN + 4;  // LDS row stride (floats) of the [128][64] K/V tile: b128-read conflict-free
+    float* Tl = smem;              // 128 * 68 floats = 34.8 KB <= main-loop LDS (reusable after its last barrier)
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + tm * 32 + mfma_row(r, half);  // 0..63 = K_h channel d, 64..127 = V_h channel q
+            const int col = wn * 32 + l31;
+            float v = acc[tm][0][r] + bqkv[256 + h * 128 + row];
+            if (row < 64) v = elu1(v) + 1.f;
+            if (col >= ts.valid) v = 0.f;  // pad columns must not enter the sums (elu(0)+1 = 1)
+            Tl[row * TS + col] = v;
+        }
+    __syncthreads();
+    {
+        // wave -> 32x32 quadrant (qi, di) of KV[q][d]; contraction over the 64 columns m
+        const int qi = wave >> 1, di = wave & 1;
+        f32x16 kv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kv[r] = 0.f;
+        const float4* ap = reinterpret_cast<const float4*>(Tl + (64 + qi * 32 + l31) * TS + half * 32);
+        const float4* bp = reinterpret_cast<const float4*>(Tl + (di * 32 + l31) * TS + half * 32);
+#pragma unroll
+        for (int v4 = 0; v4 < 8; ++v4) {
+            const float4 a = ap[v4], b = bp[v4];
+            kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, kv, 0, 0, 0);
+            kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, kv, 0, 0, 0);
+            kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, kv, 0, 0, 0);
+            kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, kv, 0, 0, 0);
+        }
+        float* out = kvpart + ((size_t)ct * H + h) * KVP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = qi * 32 + mfma_row(r, half);
+            out[q * DH + di * 32 + l31] = kv[r];
+        }
+        if (tid < DH) {
+            float s = 0.f;
+            const float* kr = Tl + tid * TS;
+            for (int m = 0; m < T::BN; ++m) s += kr[m];
+            out[DH * DH + tid] = s;
+        }
+    }
+}
+
+// K2  fixed-order sum of the KV partials of each (segment, head) -> KV[seg][h][q][d], ksum[seg][h][d]
+__global__ __launch_bounds__(256) void kv_final_kernel(const float* __restrict__ kvpart, float* __restrict__ kvfin,
+                                                       ColLayout L) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int seg = blockIdx.y / H, h = blockIdx.y % H;
+    if (e >= KVP) return;
+    const int frame = seg >> 1, side = seg & 1;
+    const int t0 = (frame * L.np + (side ? L.n1p : 0)) / QKV_BN;
+    const int nt = (side ? L.n2p : L.n1p) / QKV_BN;
+    float s = 0.f;
+    for (int t = 0; t < nt; ++t) s += kvpart[((size_t)(t0 + t) * H + h) * KVP + e];
+    kvfin[((size_t)seg * H + h) * KVP + e] = s;
+}
+
+// =====================================================================================================
+// K3  linear-attention apply:  msg_h[q][n] = z_h[n] * sum_d KV_h[q][d] Q_h[d][n],
+//     z_h[n] = 1 / (sum_d Q_h[d][n] ksum_h[d] + 1e-6)          (GATs_SuperGlue.py:78-79; the
+//     value/v_length ... *v_length pair of :74-75,79 cancels and is not evaluated)
+//     KV / ksum come from the source segment: the same segment for 'self', the other side of the
+//     same frame for 'cross' (:57,62).
+// =====================================================================================================
+using ApplyTile = GemmTile<64, 64, 2, 2, false>;
+
+__global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict__ kvfin, const float* __restrict__ Qbuf,
+                                                         float* __restrict__ MSG, ColLayout L, int cross) {
+    using T = ApplyTile;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float zs[64];
+    __shared__ float zpart[4][64];
+    const int ct = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const int c0 = ct * T::BN, ld = L.ld;
+    const TileSeg ts = tile_seg(L, c0, T::BN);
+    const int src = cross ? (ts.seg ^ 1) : ts.seg;
+    const float* KV = kvfin + ((size_t)src * H + h) * KVP;  // [q][d]
+    const float* ksum = KV + DH * DH;
+    const float* Qh = Qbuf + (size_t)h * DH * ld;
+    const int tid = threadIdx.x;
+    {
+        const int col = tid & 63, part = tid >> 6;
+        float s = 0.f;
+#pragma unroll 4
+        for (int d = part * 16; d < part * 16 + 16; ++d) s += Qh[(size_t)d * ld + c0 + col] * ksum[d];
+        zpart[part][col] = s;
+    }
+    f32x16 acc[T::TM][T::TN];
+    zero_acc(acc);
+    gemm_mainloop<T>(
+        acc, smem, DH / BK,
+        [&](int kt, int r, int c) { return *reinterpret_cast<const float4*>(KV + r * DH + kt * BK + c); },
+        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(Qh + (size_t)(kt * BK + k) * ld + c0 + c); });
+    if (tid < 64) zs[tid] = 1.f / (((zpart[0][tid] + zpart[1][tid]) + (zpart[2][tid] + zpart[3][tid])) + 1e-6f);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    const int col = wn * 32 + l31;
+    const float z = zs[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = wm * 32 + mfma_row(r, half);
+        MSG[(size_t)(h * DH + q) * ld + c0 + col] = acc[0][0][r] * z;
+    }
+}
+
+// =====================================================================================================
+// K4  mlp.0 with merge folded in:  u = W0a x + (W0b Wm) msg + (b0 + W0b bm)   [512 x N]
+//     (GATs_SuperGlue.py:101 merge, :113 cat, :122 first Conv1d) + per-tile InstanceNorm partials
+//     (sum u, sum u^2 over the tile's real columns; :126).
+// =====================================================================================================
+using Mlp0Tile = GemmTile<128, MLP0_BN, 2, 2, false>;
+
+__global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
+                                                   const float* __restrict__ Z, const float* __restrict__ MSG,
+                                                   float* __restrict__ U, float* __restrict__ statpart, ColLayout L) {
+    using T = Mlp0Tile;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int rt, ct;
+    const int NT = L.ld / T::BN;
+    if (!xcd_tile_map(4, NT, rt, ct)) return;
+    const int c0 = ct * T::BN, ld = L.ld;
+    const float* A = W0 + (size_t)rt * 128 * 512;
+    f32x16 acc[T::TM][T::TN];
+    zero_acc(acc);
+    gemm_mainloop<T>(
+        acc, smem, 512 / BK,
+        [&](int kt, int r, int c) { return *reinterpret_cast<const float4*>(A + (size_t)r * 512 + kt * BK + c); },
+        [&](int kt, int k, int c) {
+            const float* src = kt < 8 ? Z + (size_t)(kt * BK + k) * ld : MSG + (size_t)((kt - 8) * BK + k) * ld;
+            return *reinterpret_cast<const float4*>(src + c0 + c);
+        });
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    const TileSeg ts = tile_seg(L, c0, T::BN);
+    constexpr int TS = T::BN + 1;
+    float* Tl = smem;  // [128][65]
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + tm * 32 + mfma_row(r, half);
+            const int col = wn * 32 + l31;
+            const float v = acc[tm][0][r] + b0[rt * 128 + row];
+            U[(size_t)(rt * 128 + row) * ld + c0 + col] = v;
+            Tl[row * TS + col] = v;
+        }
+    __syncthreads();
+    if (tid < 128) {
+        float s = 0.f, s2 = 0.f;
+        const float* tr = Tl + tid * TS;
+        for (int m = 0; m < ts.valid; ++m) {
+            const float v = tr[m];
+            s += v;
+            s2 += v * v;
+        }
+        statpart[((size_t)ct * 2 + 0) * 512 + rt * 128 + tid] = s;
+        statpart[((size_t)ct * 2 + 1) * 512 + rt * 128 + tid] = s2;
+    }
+}
+
+// K5  InstanceNorm statistics per (segment, channel): mean and 1/sqrt(var + 1e-5), biased variance
+//     (nn.InstanceNorm1d defaults, GATs_SuperGlue.py:126).  Partials are combined in a fixed order
+//     in double precision.
+__global__ __launch_bounds__(256) void stat_final_kernel(const float* __restrict__ statpart, float* __restrict__ stats,
+                                                         ColLayout L) {
+    const int seg = blockIdx.x, row = blockIdx.y * 256 + threadIdx.x;
+    const int frame = seg >> 1, side = seg & 1;
+    const int t0 = (frame * L.np + (side ? L.n1p : 0)) / MLP0_BN;
+    const int nt = (side ? L.n2p : L.n1p) / MLP0_BN;
+    const int n = side ? L.n2 : L.n1;
+    double s = 0.0, s2 = 0.0;
+    for (int t = 0; t < nt; ++t) {
+        s += (double)statpart[((size_t)(t0 + t) * 2 + 0) * 512 + row];
+        s2 += (double)statpart[((size_t)(t0 + t) * 2 + 1) * 512 + row];
+    }
+    const double mean = s / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((size_t)seg * 2 + 0) * 512 + row] = (float)mean;
+    stats[((size_t)seg * 2 + 1) * 512 + row] = (float)(1.0 / sqrt(var + 1e-5));
+}
+
+// =====================================================================================================
+// K6  mlp.3 with the InstanceNorm + ReLU applied on the B-operand load, bias and residual add in the
+//     epilogue:  Z += W3 relu((u - mean) * rstd) + b3      (GATs_SuperGlue.py:126-128, :59,64)
+// =====================================================================================================
+using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;
+
+__global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
+                                                   const float* __restrict__ U, const float* __restrict__ stats,
+                                                   float* __restrict__ Z, ColLayout L) {
+    using T = Mlp3Tile;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int rt, ct;
+    const int NT = L.ld / T::BN;
+    if (!xcd_tile_map(4, NT, rt, ct)) return;
+    const int c0 = ct * T::BN, ld = L.ld;
+    const TileSeg ts = tile_seg(L, c0, T::BN);
+    const float* mean = stats + ((size_t)ts.seg * 2 + 0) * 512;
+    const float* rstd = stats + ((size_t)ts.seg * 2 + 1) * 512;
+    const float* A = W3 + (size_t)rt * 64 * 512;
+    f32x16 acc[T::TM][T::TN];
+    zero_acc(acc);
+    gemm_mainloop<T>(
+        acc, smem, 512 / BK,
+        [&](int kt, int r, int c) { return *reinterpret_cast<const float4*>(A + (size_t)r * 512 + kt * BK + c); },
+        [&](int kt, int k, int c) {
+            const int kr = kt * BK + k;
+            float4 v = *reinterpret_cast<const float4*>(U + (size_t)kr * ld + c0 + c);
+            const float m = mean[kr], s = rstd[kr];
+            v.x = fmaxf((v.x - m) * s, 0.f);
+            v.y = fmaxf((v.y - m) * s, 0.f);
+            v.z = fmaxf((v.z - m) * s, 0.f);
+            v.w = fmaxf((v.w - m) * s, 0.f);
+            return v;
+        });
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = rt * 64 + wm * 32 + mfma_row(r, half);
+        float* p = Z + (size_t)row * ld + c0 + wn * 32 + l31;
+        *p = *p + (acc[0][0][r] + b3[row]);
+    }
+}
+
+// =====================================================================================================
+// K7  final_proj + F.normalize(p=2, dim=channels, eps=1e-12)      (GATs_SuperGlue.py:209-213)
+//     One workgroup owns all 256 output channels of a 32-column tile, so the L2 norm is an
+//     in-block reduction.
+// =====================================================================================================
+using FinalTile = GemmTile<256, 32, 4, 1, false>;
+
+__global__ __launch_bounds__(256) void final_proj_norm_kernel(const float* __restrict__ Wf, const float* __restrict__ bf,
+                                                              const float* __restrict__ Z, float* __restrict__ MD,
+                                                              ColLayout L) {
+    using T = FinalTile;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float npart[4][32];
+    const int ct = blockIdx.x;
+    const int c0 = ct * T::BN, ld = L.ld;
+    f32x16 acc[T::TM][T::TN];
+    zero_acc(acc);
+    gemm_mainloop<T>(
+        acc, smem, D / BK,
+        [&](int kt, int r, int c) { return *reinterpret_cast<const float4*>(Wf + (size_t)r * D + kt * BK + c); },
+        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(Z + (size_t)(kt * BK + k) * ld + c0 + c); });
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    float ss = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 64 + tm * 32 + mfma_row(r, half);
+            const float v = acc[tm][0][r] + bf[row];
+            acc[tm][0][r] = v;
+            ss += v * v;
+        }
+    ss += __shfl_xor(ss, 32);
+    if (half == 0) npart[wave][l31] = ss;
+    __syncthreads();
+    const float nrm = sqrtf((npart[0][l31] + npart[1][l31]) + (npart[2][l31] + npart[3][l31]));
+    const float inv = 1.f / fmaxf(nrm, 1e-12f);
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 64 + tm * 32 + mfma_row(r, half);
+            MD[(size_t)row * ld + c0 + l31] = acc[tm][0][r] * inv;
+        }
+}
+
+// =====================================================================================================
+// K8  score contraction + exp:  E[n][m] = exp( (sum_d A[d][n] B[d][m]) / scale_factor )
+//     (GATs_SuperGlue.py:217 and the numerator of both softmaxes of :218; |score| <= 1/0.07 so the
+//     max-subtraction of softmax is not needed for range).  E is written into the conf buffer; the
+//     tile's row sums (over its 64 columns) and column sums (over its 128 rows) go to partial
+//     buffers that are reduced in a fixed order.
+// =====================================================================================================
+using ScoreTile = GemmTile<SC_BM, SC_BN, 2, 2, true>;
+
+__global__ __launch_bounds__(256) void score_exp_kernel(const float* __restrict__ MD, float* __restrict__ conf,
+                                                        float* __restrict__ rowpart, float* __restrict__ colpart,
+                                                        ColLayout L, float scale) {
+    using T = ScoreTile;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nrt = L.n1p / T::BM, nct = L.n2p / T::BN;
+    int rt, ct;
+    const int frame = blockIdx.y;
+    if (!xcd_tile_map(nrt, nct, rt, ct)) return;
+    const int ld = L.ld;
+    const float* Ap = MD + (size_t)frame * L.np + rt * T::BM;            // [K][M] with row stride ld
+    const float* Bp = MD + (size_t)frame * L.np + L.n1p + ct * T::BN;
+    f32x16 acc[T::TM][T::TN];
+    zero_acc(acc);
+    gemm_mainloop<T>(
+        acc, smem, D / BK,
+        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(Ap + (size_t)(kt * BK + k) * ld + c); },
+        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(Bp + (size_t)(kt * BK + k) * ld + c); });
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    constexpr int TS = T::BN + 1;
+    float* Tl = smem;  // [128][65]
+    float* cf = conf + (size_t)frame * L.n1 * L.n2;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + tm * 32 + mfma_row(r, half);
+            const int col = wn * 32 + l31;
+            const int gi = rt * T::BM + row, gj = ct * T::BN + col;
+            float e = 0.f;
+            if (gi < L.n1 && gj < L.n2) {
+                e = expf(acc[tm][0][r] / scale);
+                cf[(size_t)gi * L.n2 + gj] = e;
+            }
+            Tl[row * TS + col] = e;
+        }
+    __syncthreads();
+    if (tid < T::BM) {
+        float s = 0.f;
+        const float* tr = Tl + tid * TS;
+#pragma unroll 8
+        for (int m = 0; m < T::BN; ++m) s += tr[m];
+        rowpart[((size_t)frame * nct + ct) * L.n1p + rt * T::BM + tid] = s;
+    } else if (tid < T::BM + T::BN) {
+        const int c = tid - T::BM;
+        float s = 0.f;
+#pragma unroll 8
+        for (int m = 0; m < T::BM; ++m) s += Tl[m * TS + c];
+        colpart[((size_t)frame * nrt + rt) * L.n2p + ct * T::BN + c] = s;
+    }
+}
+
+// =====================================================================================================
+// Generic dense GEMM used off the hot path (GATs with_linear_transform=True:  out = elu(W^T pre (+h)) ).
+//   C[256][cols of Y segments] = elu( sum_c W[c][o] * P[c][n]  (+ R[o][n]) )       (GATs.py:57,62,65,70)
+// =====================================================================================================
+using WltTile = GemmTile<64, 64, 2, 2, true>;
+
+__global__ __launch_bounds__(256) void gats_wlt_kernel(const float* __restrict__ W, const float* __restrict__ P,
+                                                       float* __restrict__ Z, ColLayout L, int add_h) {
+    using T = WltTile;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int rt, ct;
+    const int NT = L.ld / T::BN;
+    if (!xcd_tile_map(4, NT, rt, ct)) return;
+    const int c0 = ct * T::BN, ld = L.ld;
+    const TileSeg ts = tile_seg(L, c0, T::BN);
+    if (ts.side == 0) return;  // only the 3D side is touched by a GATs layer
+    f32x16 acc[T::TM][T::TN];
+    zero_acc(acc);
+    gemm_mainloop<T>(
+        acc, smem, D / BK,
+        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(W + (size_t)(kt * BK + k) * D + rt * 64 + c); },
+        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(P + (size_t)(kt * BK + k) * ld + c0 + c); });
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = rt * 64 + wm * 32 + mfma_row(r, half);
+        float* p = Z + (size_t)row * ld + c0 + wn * 32 + l31;
+        float v = acc[0][0][r];
+        if (add_h) v += *p;
+        *p = elu1(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------------
+template <class T>
+constexpr size_t smem_bytes() { return sizeof(float) * T::SMEM_FLOATS; }
+
+void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    const int NT = w.L.ld / QkvTile::BN;
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, qkv_kv_kernel, dim3(xcd_grid(6, NT)), dim3(256), smem_bytes<QkvTile>(), s, Wqkv, bqkv,
+                   w.Z, w.Q, w.kvpart, w.L);
+    GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3((KVP + 255) / 256, w.nseg * H), dim3(256), 0, s, w.kvpart,
+                   w.kvfin, w.L);
+}
+
+void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook* hk) {
+    const int NT = w.L.ld / ApplyTile::BN;
+    GATSSPG_LAUNCH(hk, KID_ATTN_APPLY, s, attn_apply_kernel, dim3(NT * H), dim3(256), smem_bytes<ApplyTile>(), s, w.kvfin, w.Q,
+                   w.MSG, w.L, cross);
+}
+
+void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const Workspace& w, hipStream_t s,
+                ProfileHook* hk) {
+    const int NT = w.L.ld / Mlp0Tile::BN;
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, mlp0_kernel, dim3(xcd_grid(4, NT)), dim3(256), smem_bytes<Mlp0Tile>(), s, W0, b0, w.Z,
+                   w.MSG, w.U, w.statpart, w.L);
+    GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 2), dim3(256), 0, s, w.statpart, w.stats, w.L);
+    GATSSPG_LAUNCH(hk, KID_MLP3, s, mlp3_kernel, dim3(xcd_grid(4, NT)), dim3(256), smem_bytes<Mlp3Tile>(), s, W3, b3, w.U,
+                   w.stats, w.Z, w.L);
+}
+
+void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    GATSSPG_LAUNCH(hk, KID_FINAL_PROJ, s, final_proj_norm_kernel, dim3(w.L.ld / FinalTile::BN), dim3(256),
+                   smem_bytes<FinalTile>(), s, Wf, bf, w.Z, w.MD, w.L);
+}
+
+void launch_score_exp(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk) {
+    GATSSPG_LAUNCH(hk, KID_SCORE_EXP, s, score_exp_kernel, dim3(xcd_grid(w.sc_nrt, w.sc_nct), w.L.b), dim3(256),
+                   smem_bytes<ScoreTile>(), s, w.MD, conf, w.rowpart, w.colpart, w.L, scale);
+}
+
+void launch_gats_wlt(const float* W, const float* P, const Workspace& w, int add_h, hipStream_t s, ProfileHook* hk) {
+    const int NT = w.L.ld / WltTile::BN;
+    GATSSPG_LAUNCH(hk, KID_GATS_WLT, s, gats_wlt_kernel, dim3(xcd_grid(4, NT)), dim3(256), smem_bytes<WltTile>(), s, W, P, w.Z,
+                   w.L, add_h);
+}
+
+}  // namespace gatsspg

@@ -1,0 +1,57 @@
+// Host-side launcher prototypes shared between the kernel translation units and the C ABI.
+#pragma once
+#include "gatsspg_common.h"
+
+namespace gatsspg {
+
+// Kernel ids (also the `kernel_id` of gatsspg_forward_profiled, include/gatsspg.h)
+enum KernelId {
+    KID_LOAD_STATE = 0, KID_GATS = 1, KID_QKV_KV = 2, KID_KV_FINAL = 3, KID_ATTN_APPLY = 4, KID_MLP0 = 5,
+    KID_STAT_FINAL = 6, KID_MLP3 = 7, KID_FINAL_PROJ = 8, KID_SCORE_EXP = 9, KID_SOFTMAX_SUMS = 10,
+    KID_CONF_FINALIZE = 11, KID_MATCH_REDUCE = 12, KID_MATCH_TAIL = 13, KID_GATS_WLT = 14, KID_COUNT = 15
+};
+
+// Optional HIP-event bracket around the `occurrence`-th launch of kernel `kernel_id` inside one forward
+// (events live on the same stream as the kernels).  nullptr = no instrumentation.
+struct ProfileHook {
+    int kernel_id, occurrence;
+    hipEvent_t start, stop;
+    int seen[KID_COUNT];
+};
+inline bool hook_hit(ProfileHook* h, int kid) { return h && h->kernel_id == kid && h->seen[kid] == h->occurrence; }
+inline void hook_before(ProfileHook* h, int kid, hipStream_t s) {
+    if (hook_hit(h, kid)) (void)hipEventRecord(h->start, s);
+}
+inline void hook_after(ProfileHook* h, int kid, hipStream_t s) {
+    if (hook_hit(h, kid)) (void)hipEventRecord(h->stop, s);
+    if (h) h->seen[kid]++;
+}
+#define GATSSPG_LAUNCH(hook, kid, stream, ...)      \
+    do {                                            \
+        hook_before(hook, kid, stream);             \
+        hipLaunchKernelGGL(__VA_ARGS__);            \
+        hook_after(hook, kid, stream);              \
+    } while (0)
+
+// gatsspg_gemm_kernels.hip
+void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_score_exp(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_gats_wlt(const float* W, const float* P, const Workspace& w, int add_h, hipStream_t s, ProfileHook* hk = nullptr);
+
+// gatsspg_stream_kernels.hip
+void launch_load_state(const float* dq, const float* d3, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_store_state(const float* src, float* out2d, float* out3d, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_gats(const float* u1, const float* u2, const float* leaves, int num_leaf, int flags, float* dst,
+                 const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_dual_softmax_match(const Workspace& w, float* conf, float match_threshold, int64_t* matches0,
+                               int64_t* matches1, float* mscores0, float* mscores1, hipStream_t s,
+                               ProfileHook* hk = nullptr);
+void launch_pack_weights(const void* raw_struct_host, float* packed, hipStream_t s);
+size_t kenc_scratch_bytes(int b, int n);
+void launch_kenc(const float* const* w, const float* const* bias, int inp_dim, const float* kpts, const float* scores,
+                 int b, int n, float* out, void* scratch, hipStream_t s);
+
+}  // namespace gatsspg

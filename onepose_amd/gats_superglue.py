@@ -1,0 +1,350 @@
+"""Drop-in ``GATsSuperGlue`` for the OnePose GATsSPG 2D-3D matcher, running on hand-written HIP
+kernels (MI355X / gfx950) through the C ABI of libgatsspg_hip.so.
+
+Mirrors the reference module's interface (src/models/GATsSPG_architectures/GATs_SuperGlue.py:143-241):
+same constructor (``hparams`` mapping), same parameter names and shapes (so the ``matcher.*`` tensors
+of a GATsSPG.ckpt load with ``strict=True``), same ``forward(data) -> (pred, conf_matrix)`` contract,
+including the reference's quirks: ``pred`` carries batch element 0 only (:232-237), an empty side
+returns a bare dict with int32 matches (:195-203), a single keypoint raises ``ValueError`` (what
+``nn.InstanceNorm1d`` does in the reference, :126), the keypoint encoders and ``bin_score`` are
+parameters that forward never uses (:150-160,176-177).
+
+The sub-modules below are parameter containers; all arithmetic happens in the HIP library.  There is
+no PyTorch / CPU fallback: tensors that are not on a ROCm device raise.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _native
+
+D = 256
+NUM_HEADS = 4
+GNN_LAYER_NAMES = ["GATs", "self", "cross"] * 4  # GATs_SuperGlue.py:162
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter containers (names/shapes = reference state_dict)
+# --------------------------------------------------------------------------------------------------
+class GraphAttentionLayer(nn.Module):
+    """Parameters of GATs.py:25-28: W [in,out] (applied on the right, h @ W), a [2*out, 1]."""
+
+    def __init__(self, in_features=D, out_features=D, alpha=0.2, include_self=True, additional=False,
+                 with_linear_transform=True):
+        super().__init__()
+        self.alpha = alpha
+        self.include_self, self.additional, self.with_linear_transform = include_self, additional, with_linear_transform
+        self.W = nn.Parameter(torch.empty(in_features, out_features))
+        self.a = nn.Parameter(torch.empty(2 * out_features, 1))
+        nn.init.xavier_normal_(self.W.data, gain=1.414)
+        nn.init.xavier_normal_(self.a.data, gain=1.414)
+
+
+class MultiHeadedAttention(nn.Module):
+    """merge + proj.{0,1,2} 1x1 convolutions (GATs_SuperGlue.py:85-91)."""
+
+    def __init__(self, num_heads, d_model):
+        super().__init__()
+        assert d_model % num_heads == 0
+        self.dim, self.num_heads = d_model // num_heads, num_heads
+        self.merge = nn.Conv1d(d_model, d_model, kernel_size=1)
+        self.proj = nn.ModuleList([nn.Conv1d(d_model, d_model, kernel_size=1) for _ in range(3)])
+        for p in self.proj:  # the reference deep-copies merge three times (:91): identical initial values
+            p.load_state_dict(self.merge.state_dict())
+
+
+def _mlp(channels):
+    """Conv1d / InstanceNorm1d / ReLU stack with the reference's Sequential indices (:116-128)."""
+    layers = []
+    for i in range(1, len(channels)):
+        layers.append(nn.Conv1d(channels[i - 1], channels[i], kernel_size=1, bias=True))
+        if i < len(channels) - 1:
+            layers.append(nn.InstanceNorm1d(channels[i]))
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+class AttentionPropagation(nn.Module):
+    def __init__(self, feature_dim, num_heads):
+        super().__init__()
+        self.attn = MultiHeadedAttention(num_heads, feature_dim)
+        self.mlp = _mlp([feature_dim * 2, feature_dim * 2, feature_dim])
+        nn.init.constant_(self.mlp[-1].bias, 0.0)
+
+
+class AttentionalGNN(nn.Module):
+    def __init__(self, feature_dim, layer_names, include_self, additional, with_linear_transform):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            GraphAttentionLayer(D, D, 0.2, include_self, additional, with_linear_transform) if i % 3 == 0
+            else AttentionPropagation(feature_dim, NUM_HEADS) for i in range(len(layer_names))])
+        self.names = layer_names
+
+
+class KeypointEncoder(nn.Module):
+    """MLP([inp, *layers, feature_dim]) on cat([kpts^T, scores]) (GATs_SuperGlue.py:131-140).
+    Built by the reference but never called by its forward; callable here as a standalone HIP op."""
+
+    def __init__(self, inp_dim, feature_dim, layers):
+        super().__init__()
+        self.inp_dim = inp_dim
+        self.encoder = _mlp([inp_dim] + list(layers) + [feature_dim])
+        nn.init.constant_(self.encoder[-1].bias, 0.0)
+
+    def forward(self, kpts, scores):
+        if list(self.encoder[0].weight.shape[:1]) != [32] or len(self.encoder) != 10:
+            raise NotImplementedError("HIP KeypointEncoder supports the shipped layout [inp,32,64,128,256]")
+        lib = _native.load()
+        kpts = _require_gpu(kpts.float().contiguous(), "kpts")
+        scores = scores.float().contiguous()
+        b, n = kpts.shape[0], kpts.shape[1]
+        if n < 2:
+            raise ValueError(f"Expected more than 1 spatial element when training, got input size {[b, 32, n]}")
+        kw = _native.KencWeights()
+        keep = []
+        for j, idx in enumerate((0, 3, 6, 9)):
+            w = self.encoder[idx].weight.detach().float().contiguous()
+            bb = self.encoder[idx].bias.detach().float().contiguous()
+            keep += [w, bb]
+            kw.w[j], kw.b[j] = w.data_ptr(), bb.data_ptr()
+        kw.inp_dim = self.inp_dim
+        out = torch.empty(b, D, n, device=kpts.device, dtype=torch.float32)
+        nbytes = lib.gatsspg_kenc_scratch_bytes(b, n)
+        scratch = torch.empty(nbytes, device=kpts.device, dtype=torch.uint8)
+        _native.check(lib.gatsspg_keypoint_encoder(ctypes.byref(kw), kpts.data_ptr(), scores.data_ptr(), b, n,
+                                                   out.data_ptr(), scratch.data_ptr(), nbytes, _stream(kpts.device)),
+                      "gatsspg_keypoint_encoder")
+        return out
+
+
+def _require_gpu(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"onepose_amd.GATsSuperGlue runs only on a ROCm GPU (tensor '{name}' is on {t.device}); "
+            "there is no CPU fallback -- move the module and its inputs to the GPU")
+    return t
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# --------------------------------------------------------------------------------------------------
+# the engine: packed weights + workspace + stage calls (also used by the per-kernel parity tests)
+# --------------------------------------------------------------------------------------------------
+class GATsSPGEngine:
+    """Owns the device-side packed weights and workspaces of one module on one device."""
+
+    def __init__(self, module):
+        self.module = module
+        self.lib = _native.load()
+        self._packed = None
+        self._packed_key = None
+        self._ws = {}
+
+    # ---- weights ----
+    def _raw_tensors(self):
+        m = self.module
+        out = []
+        for i, name in enumerate(GNN_LAYER_NAMES):
+            layer = m.gnn.layers[i]
+            if name == "GATs":
+                out += [layer.W, layer.a]
+            else:
+                out += [layer.attn.proj[0].weight, layer.attn.proj[0].bias, layer.attn.proj[1].weight,
+                        layer.attn.proj[1].bias, layer.attn.proj[2].weight, layer.attn.proj[2].bias,
+                        layer.attn.merge.weight, layer.attn.merge.bias, layer.mlp[0].weight, layer.mlp[0].bias,
+                        layer.mlp[3].weight, layer.mlp[3].bias]
+        out += [m.final_proj.weight, m.final_proj.bias]
+        return out
+
+    def packed_weights(self, device):
+        params = self._raw_tensors()
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        for p in params:
+            _require_gpu(p, "parameter")
+        keep = [p.detach().to(device=device, dtype=torch.float32).contiguous() for p in params]
+        raw = _native.RawWeights()
+        it = iter(keep)
+        gi = ai = 0
+        for name in GNN_LAYER_NAMES:
+            if name == "GATs":
+                raw.gats_W[gi], raw.gats_a[gi] = next(it).data_ptr(), next(it).data_ptr()
+                gi += 1
+            else:
+                for j in range(3):
+                    raw.proj_w[ai][j], raw.proj_b[ai][j] = next(it).data_ptr(), next(it).data_ptr()
+                raw.merge_w[ai], raw.merge_b[ai] = next(it).data_ptr(), next(it).data_ptr()
+                raw.mlp0_w[ai], raw.mlp0_b[ai] = next(it).data_ptr(), next(it).data_ptr()
+                raw.mlp3_w[ai], raw.mlp3_b[ai] = next(it).data_ptr(), next(it).data_ptr()
+                ai += 1
+        raw.final_w, raw.final_b = next(it).data_ptr(), next(it).data_ptr()
+        packed = torch.empty(self.lib.gatsspg_packed_weights_bytes() // 4, device=device, dtype=torch.float32)
+        _native.check(self.lib.gatsspg_pack_weights(ctypes.byref(raw), packed.data_ptr(), _stream(device)),
+                      "gatsspg_pack_weights")
+        self._packed, self._packed_key = packed, key
+        return packed
+
+    # ---- workspace ----
+    def workspace(self, b, n1, n2, num_leaf, device):
+        key = (b, n1, n2, num_leaf, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = self.lib.gatsspg_workspace_bytes(b, n1, n2, num_leaf)
+            if nbytes == 0:
+                raise _native.NativeError("gatsspg_workspace_bytes: " + self.lib.gatsspg_last_error().decode())
+            if len(self._ws) >= 4:
+                self._ws.clear()
+            ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
+            self._ws[key] = ws
+        return ws
+
+    def flags(self):
+        hp = self.module.hparams
+        return ((_native.FLAG_INCLUDE_SELF if hp["include_self"] else 0)
+                | (_native.FLAG_ADDITIONAL if hp["additional"] else 0)
+                | (_native.FLAG_WITH_LINEAR_TRANSFORM if hp["with_linear_transform"] else 0))
+
+    # ---- whole forward, all b samples ----
+    def forward(self, dq, d3, d2db, scale_factor, match_threshold):
+        b, _, n1 = dq.shape
+        n2 = d3.shape[2]
+        num_leaf = d2db.shape[2] // n2
+        dev = dq.device
+        packed = self.packed_weights(dev)
+        ws = self.workspace(b, n1, n2, num_leaf, dev)
+        conf = torch.empty(b, n1, n2, device=dev, dtype=torch.float32)
+        m0 = torch.empty(b, n1, device=dev, dtype=torch.int64)
+        m1 = torch.empty(b, n2, device=dev, dtype=torch.int64)
+        s0 = torch.empty(b, n1, device=dev, dtype=torch.float32)
+        s1 = torch.empty(b, n2, device=dev, dtype=torch.float32)
+        _native.check(self.lib.gatsspg_forward(
+            packed.data_ptr(), dq.data_ptr(), d3.data_ptr(), d2db.data_ptr(), b, n1, n2, num_leaf, self.flags(),
+            float(scale_factor), float(match_threshold), conf.data_ptr(), m0.data_ptr(), m1.data_ptr(), s0.data_ptr(),
+            s1.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "gatsspg_forward")
+        return conf, m0, m1, s0, s1
+
+    # ---- stages (parity tests) ----
+    def load_state(self, dq, d3, num_leaf):
+        b, _, n1 = dq.shape
+        n2 = d3.shape[2]
+        ws = self.workspace(b, n1, n2, num_leaf, dq.device)
+        _native.check(self.lib.gatsspg_load_state(dq.data_ptr(), d3.data_ptr(), b, n1, n2, num_leaf, ws.data_ptr(),
+                                                  ws.numel(), _stream(dq.device)), "gatsspg_load_state")
+        return (b, n1, n2, num_leaf, dq.device)
+
+    def store_state(self, dims, which=0):
+        b, n1, n2, num_leaf, dev = dims
+        ws = self.workspace(*dims)
+        o2 = torch.empty(b, D, n1, device=dev, dtype=torch.float32)
+        o3 = torch.empty(b, D, n2, device=dev, dtype=torch.float32)
+        _native.check(self.lib.gatsspg_store_state(which, o2.data_ptr(), o3.data_ptr(), b, n1, n2, num_leaf,
+                                                   ws.data_ptr(), ws.numel(), _stream(dev)), "gatsspg_store_state")
+        return o2, o3
+
+    def gats_layer(self, dims, layer, d2db, flags=None):
+        b, n1, n2, num_leaf, dev = dims
+        ws = self.workspace(*dims)
+        _native.check(self.lib.gatsspg_gats_layer(self.packed_weights(dev).data_ptr(), layer, d2db.data_ptr(), b, n1, n2,
+                                                  num_leaf, self.flags() if flags is None else flags, ws.data_ptr(),
+                                                  ws.numel(), _stream(dev)), "gatsspg_gats_layer")
+
+    def attn_layer(self, dims, layer, kind):
+        b, n1, n2, num_leaf, dev = dims
+        ws = self.workspace(*dims)
+        _native.check(self.lib.gatsspg_attn_layer(self.packed_weights(dev).data_ptr(), layer, kind, b, n1, n2, num_leaf,
+                                                  ws.data_ptr(), ws.numel(), _stream(dev)), "gatsspg_attn_layer")
+
+    def final_proj_norm(self, dims):
+        b, n1, n2, num_leaf, dev = dims
+        ws = self.workspace(*dims)
+        _native.check(self.lib.gatsspg_final_proj_norm(self.packed_weights(dev).data_ptr(), b, n1, n2, num_leaf,
+                                                       ws.data_ptr(), ws.numel(), _stream(dev)), "gatsspg_final_proj_norm")
+
+    def score_match(self, dims, scale_factor, match_threshold):
+        b, n1, n2, num_leaf, dev = dims
+        ws = self.workspace(*dims)
+        conf = torch.empty(b, n1, n2, device=dev, dtype=torch.float32)
+        m0 = torch.empty(b, n1, device=dev, dtype=torch.int64)
+        m1 = torch.empty(b, n2, device=dev, dtype=torch.int64)
+        s0 = torch.empty(b, n1, device=dev, dtype=torch.float32)
+        s1 = torch.empty(b, n2, device=dev, dtype=torch.float32)
+        _native.check(self.lib.gatsspg_score_dual_softmax_match(
+            b, n1, n2, num_leaf, float(scale_factor), float(match_threshold), conf.data_ptr(), m0.data_ptr(),
+            m1.data_ptr(), s0.data_ptr(), s1.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+            "gatsspg_score_dual_softmax_match")
+        return conf, m0, m1, s0, s1
+
+
+# --------------------------------------------------------------------------------------------------
+# the drop-in module
+# --------------------------------------------------------------------------------------------------
+class GATsSuperGlue(nn.Module):
+    """HIP implementation behind the reference ``GATsSuperGlue`` API (GATs_SuperGlue.py:143-241)."""
+
+    def __init__(self, hparams):
+        super().__init__()
+        self.hparams = hparams
+        self.match_type = hparams["match_type"]
+        if hparams["descriptor_dim"] != D:
+            raise NotImplementedError("descriptor_dim must be 256 (the reference GNN hard-codes it, :35-36)")
+        self.kenc_2d = KeypointEncoder(3, hparams["descriptor_dim"], hparams["keypoints_encoder"])
+        self.kenc_3d = KeypointEncoder(4, hparams["descriptor_dim"], hparams["keypoints_encoder"])
+        self.gnn = AttentionalGNN(hparams["descriptor_dim"], GNN_LAYER_NAMES, hparams["include_self"],
+                                  hparams["additional"], hparams["with_linear_transform"])
+        self.final_proj = nn.Conv1d(hparams["descriptor_dim"], hparams["descriptor_dim"], kernel_size=1, bias=True)
+        self.register_parameter("bin_score", nn.Parameter(torch.tensor(1.0)))
+        self._engine = None
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = GATsSPGEngine(self)  # loads the HIP library; raises if it is not built
+        return self._engine
+
+    def _inputs(self, data):
+        kpts2d, kpts3d = data["keypoints2d"].float(), data["keypoints3d"].float()
+        dq = data["descriptors2d_query"].float()
+        d3, d2db = data["descriptors3d_db"].float(), data["descriptors2d_db"].float()
+        return kpts2d, kpts3d, dq, d3, d2db
+
+    def forward_batched(self, data):
+        """All b samples: returns (conf [b,n1,n2], matches0 [b,n1], matches1 [b,n2], mscores0, mscores1).
+        The reference has no such path (its ``pred`` is sample 0 only); used for batched throughput."""
+        if self.match_type != "softmax":
+            raise NotImplementedError
+        _, _, dq, d3, d2db = self._inputs(data)
+        dq, d3, d2db = (_require_gpu(t.contiguous(), n) for t, n in
+                        ((dq, "descriptors2d_query"), (d3, "descriptors3d_db"), (d2db, "descriptors2d_db")))
+        n1, n2 = dq.shape[2], d3.shape[2]
+        if n1 == 1 or n2 == 1:  # what nn.InstanceNorm1d raises inside the reference MLP (:126)
+            raise ValueError(f"Expected more than 1 spatial element when training, got input size {[dq.shape[0], 512, 1]}")
+        if dq.shape[1] != D or d3.shape[1] != D or d2db.shape[1] != D:
+            raise ValueError("descriptors must have 256 channels")
+        if d2db.shape[2] % n2 != 0 or d2db.shape[2] == 0:
+            raise ValueError(f"descriptors2d_db has {d2db.shape[2]} leaves for {n2} 3D points: not a multiple")
+        with torch.no_grad():
+            return self.engine.forward(dq, d3, d2db, self.hparams["scale_factor"], self.hparams["match_threshold"])
+
+    def forward(self, data):
+        """Keys of ``data`` as in the reference docstring (:181-189); extra keys are ignored."""
+        kpts2d, kpts3d, _, _, _ = self._inputs(data)
+        if kpts2d.shape[1] == 0 or kpts3d.shape[1] == 0:  # :195-203
+            shape0, shape1 = kpts2d.shape[:-1], kpts3d.shape[:-1]
+            return {
+                "matches0": kpts2d.new_full(shape0, -1, dtype=torch.int)[0],
+                "matches1": kpts3d.new_full(shape1, -1, dtype=torch.int)[0],
+                "matching_scores0": kpts2d.new_zeros(shape0)[0],
+                "matching_scores1": kpts3d.new_zeros(shape1)[0],
+                "skip_train": True,
+            }
+        if self.match_type != "softmax":
+            raise NotImplementedError  # :238-239
+        conf, m0, m1, s0, s1 = self.forward_batched(data)
+        pred = {"matches0": m0[0], "matches1": m1[0], "matching_scores0": s0[0], "matching_scores1": s1[0]}
+        return pred, conf

@@ -1,0 +1,86 @@
+"""Drop-in boundary checks that need no GPU: parameter names/shapes (state_dict layout of the
+reference), hparams handling, the empty-input early return, loud failure on CPU."""
+import numpy as np
+import pytest
+import torch
+
+from onepose_amd import GATsSuperGlue, synthetic
+from onepose_amd.gats_superglue import GNN_LAYER_NAMES
+
+HP = {"descriptor_dim": 256, "keypoints_encoder": [32, 64, 128], "match_type": "softmax", "scale_factor": 0.07,
+      "match_threshold": 0.2, "include_self": True, "additional": False, "with_linear_transform": False}
+
+
+def test_state_dict_layout_matches_reference():
+    model = GATsSuperGlue(HP)
+    sd = model.state_dict()
+    ref = synthetic.make_state_dict(0)  # names/shapes verified against the reference module by make_golden.py
+    assert len(sd) == 123
+    assert set(sd) == set(ref)
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        assert sd[k].dtype == torch.float32
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()}, strict=True)
+    # Lightning checkpoint layout: 'matcher.' prefix strip, strict load
+    ck = {"matcher." + k: torch.from_numpy(v) for k, v in ref.items()}
+    model.load_state_dict({k[len("matcher."):]: v for k, v in ck.items()}, strict=True)
+    assert GNN_LAYER_NAMES == ["GATs", "self", "cross"] * 4
+
+
+def test_constructor_contract():
+    m = GATsSuperGlue(HP)
+    assert m.hparams is HP and m.match_type == "softmax"
+    # last MLP biases are zero-initialised like the reference (:109, :136)
+    for i in (1, 2, 4, 5, 7, 8, 10, 11):
+        assert float(m.gnn.layers[i].mlp[3].bias.abs().max()) == 0.0
+    assert float(m.kenc_2d.encoder[9].bias.abs().max()) == 0.0
+    # the three projections start as copies of merge (deepcopy in the reference, :91)
+    a = m.gnn.layers[1].attn
+    assert torch.equal(a.proj[0].weight, a.merge.weight) and torch.equal(a.proj[2].bias, a.merge.bias)
+    with pytest.raises(KeyError):
+        GATsSuperGlue({"match_type": "softmax"})
+    with pytest.raises(NotImplementedError):
+        GATsSuperGlue(dict(HP, descriptor_dim=128))
+
+
+def test_empty_input_returns_reference_dict(golden_meta):
+    m = GATsSuperGlue(HP).eval()
+    data = {k: torch.from_numpy(v) for k, v in synthetic.make_inputs(1, 0, 5, 8, seed=3).items()}
+    out = m(data)
+    meta = golden_meta["empty"]
+    assert isinstance(out, dict) and set(out) == set(meta) and out["skip_train"] is True
+    for k in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+        assert list(out[k].shape) == meta[k][0] and str(out[k].dtype) == meta[k][1]
+    assert bool((out["matches1"] == -1).all())
+
+
+def test_cpu_tensors_fail_loudly():
+    m = GATsSuperGlue(HP).eval()
+    data = {k: torch.from_numpy(v) for k, v in synthetic.make_inputs(1, 8, 8, 8, seed=3).items()}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(data)
+    sinkhorn = GATsSuperGlue(dict(HP, match_type="sinkhorn"))
+    with pytest.raises(NotImplementedError):
+        sinkhorn(data)
+
+
+def test_single_point_raises_like_reference(golden_meta):
+    assert golden_meta["single_point_raises"] == "ValueError"
+    m = GATsSuperGlue(HP).eval()
+    data = {k: torch.from_numpy(v) for k, v in synthetic.make_inputs(1, 1, 2, 8, seed=6).items()}
+    if torch.cuda.is_available():
+        data = {k: v.cuda() for k, v in data.items()}
+        m = m.cuda()
+        with pytest.raises(ValueError):
+            m(data)
+    else:
+        with pytest.raises((ValueError, RuntimeError)):
+            m(data)
+
+
+def test_synthetic_generators_are_deterministic():
+    a, b = synthetic.make_inputs(1, 5, 7, 8, seed=9), synthetic.make_inputs(1, 5, 7, 8, seed=9)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    np.testing.assert_allclose(np.linalg.norm(a["descriptors2d_db"], axis=1), 1.0, rtol=1e-5)
+    assert a["descriptors2d_db"].shape == (1, 256, 56)
