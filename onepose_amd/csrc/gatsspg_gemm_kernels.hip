@@ -429,6 +429,14 @@ __global__ __launch_bounds__(256) void gats_wlt_kernel(const float* __restrict__
 template <class T>
 constexpr size_t smem_bytes() { return sizeof(float) * T::SMEM_FLOATS; }
 
+// kernels whose dynamic LDS exceeds the 64 KiB default need the limit raised once per process
+template <class K>
+void allow_big_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bytes);
+}
+
 void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     const int NT = w.L.ld / QkvTile::BN;
     GATSSPG_LAUNCH(hk, KID_QKV_KV, s, qkv_kv_kernel, dim3(xcd_grid(6, NT)), dim3(256), smem_bytes<QkvTile>(), s, Wqkv, bqkv,
@@ -454,6 +462,8 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
 }
 
 void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    static const bool once = (allow_big_lds(final_proj_norm_kernel, smem_bytes<FinalTile>()), true);
+    (void)once;
     GATSSPG_LAUNCH(hk, KID_FINAL_PROJ, s, final_proj_norm_kernel, dim3(w.L.ld / FinalTile::BN), dim3(256),
                    smem_bytes<FinalTile>(), s, Wf, bf, w.Z, w.MD, w.L);
 }
