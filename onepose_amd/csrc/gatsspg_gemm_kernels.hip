@@ -4,6 +4,7 @@
 // AttentionPropagation, MLP) and :209-218 (final_proj, normalize, score einsum, exp of the softmax).
 #include "gemm_f32_mfma.h"
 #include "gatsspg_launch.h"
+#include <stdlib.h>
 
 namespace gatsspg {
 
@@ -96,18 +97,32 @@ __global__ __launch_bounds__(256) void qkv_kv_kernel(const float* __restrict__ W
     }
 }
 
-// K2  fixed-order sum of the KV partials of each (segment, head) -> KV[seg][h][q][d], ksum[seg][h][d]
-__global__ __launch_bounds__(256) void kv_final_kernel(const float* __restrict__ kvpart, float* __restrict__ kvfin,
-                                                       ColLayout L) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+// K2  fixed-order sum of the KV partials of each (segment, head) -> KV[seg][h][q][d], ksum[seg][h][d].
+//     1024 threads = 64 elements x 16 tile-ranges: every range is summed in tile order by one wave
+//     (independent loads, one latency), the 16 range sums are combined in range order -> the result
+//     does not depend on scheduling.
+__global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict__ kvpart, float* __restrict__ kvfin,
+                                                        ColLayout L) {
+    __shared__ float red[16][64];
+    const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
     const int seg = blockIdx.y / H, h = blockIdx.y % H;
-    if (e >= KVP) return;
     const int frame = seg >> 1, side = seg & 1;
     const int t0 = (frame * L.np + (side ? L.n1p : 0)) / QKV_BN;
     const int nt = (side ? L.n2p : L.n1p) / QKV_BN;
+    const int per = (nt + 15) / 16;
+    const int tb = part * per, te = min(nt, tb + per);
     float s = 0.f;
-    for (int t = 0; t < nt; ++t) s += kvpart[((size_t)(t0 + t) * H + h) * KVP + e];
-    kvfin[((size_t)seg * H + h) * KVP + e] = s;
+#pragma unroll 8
+    for (int t = tb; t < te; ++t) s += kvpart[((size_t)(t0 + t) * H + h) * KVP + e];
+    red[part][el] = s;
+    __syncthreads();
+    if (part == 0) {
+        float tot = red[0][el];
+#pragma unroll
+        for (int p = 1; p < 16; ++p) tot += red[p][el];
+        kvfin[((size_t)seg * H + h) * KVP + e] = tot;
+    }
 }
 
 // =====================================================================================================
@@ -164,18 +179,21 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
 //     (GATs_SuperGlue.py:101 merge, :113 cat, :122 first Conv1d) + per-tile InstanceNorm partials
 //     (sum u, sum u^2 over the tile's real columns; :126).
 // =====================================================================================================
+// tile variants (BN is fixed to MLP0_BN = 64: one InstanceNorm partial per 64-column tile)
 using Mlp0Tile = GemmTile<128, MLP0_BN, 2, 2, false>;
+using Mlp0TileWide = GemmTile<256, MLP0_BN, 4, 1, false>;
 
+template <class T>
 __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                    const float* __restrict__ Z, const float* __restrict__ MSG,
                                                    float* __restrict__ U, float* __restrict__ statpart, ColLayout L) {
-    using T = Mlp0Tile;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int rt, ct;
     const int NT = L.ld / T::BN;
-    if (!xcd_tile_map(4, NT, rt, ct)) return;
+    constexpr int MT = 512 / T::BM;
+    if (!xcd_tile_map(MT, NT, rt, ct)) return;
     const int c0 = ct * T::BN, ld = L.ld;
-    const float* A = W0 + (size_t)rt * 128 * 512;
+    const float* A = W0 + (size_t)rt * T::BM * 512;
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     gemm_mainloop<T>(
@@ -189,19 +207,21 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
     const TileSeg ts = tile_seg(L, c0, T::BN);
     constexpr int TS = T::BN + 1;
-    float* Tl = smem;  // [128][65]
+    float* Tl = smem;  // [BM][65]
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * 64 + tm * 32 + mfma_row(r, half);
-            const int col = wn * 32 + l31;
-            const float v = acc[tm][0][r] + b0[rt * 128 + row];
-            U[(size_t)(rt * 128 + row) * ld + c0 + col] = v;
-            Tl[row * TS + col] = v;
-        }
+        for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);
+                const int col = (wn * T::TN + tn) * 32 + l31;
+                const float v = acc[tm][tn][r] + b0[rt * T::BM + row];
+                U[(size_t)(rt * T::BM + row) * ld + c0 + col] = v;
+                Tl[row * TS + col] = v;
+            }
     __syncthreads();
-    if (tid < 128) {
+    if (tid < T::BM) {
         float s = 0.f, s2 = 0.f;
         const float* tr = Tl + tid * TS;
         for (int m = 0; m < ts.valid; ++m) {
@@ -209,31 +229,48 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
             s += v;
             s2 += v * v;
         }
-        statpart[((size_t)ct * 2 + 0) * 512 + rt * 128 + tid] = s;
-        statpart[((size_t)ct * 2 + 1) * 512 + rt * 128 + tid] = s2;
+        statpart[((size_t)ct * 2 + 0) * 512 + rt * T::BM + tid] = s;
+        statpart[((size_t)ct * 2 + 1) * 512 + rt * T::BM + tid] = s2;
     }
 }
 
 // K5  InstanceNorm statistics per (segment, channel): mean and 1/sqrt(var + 1e-5), biased variance
 //     (nn.InstanceNorm1d defaults, GATs_SuperGlue.py:126).  Partials are combined in a fixed order
-//     in double precision.
-__global__ __launch_bounds__(256) void stat_final_kernel(const float* __restrict__ statpart, float* __restrict__ stats,
-                                                         ColLayout L) {
-    const int seg = blockIdx.x, row = blockIdx.y * 256 + threadIdx.x;
+//     (64 channels x 16 tile-ranges per block, ranges combined in order) in double precision.
+__global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restrict__ statpart, float* __restrict__ stats,
+                                                          ColLayout L) {
+    __shared__ double red[2][16][64];
+    const int rl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int seg = blockIdx.x, row = blockIdx.y * 64 + rl;
     const int frame = seg >> 1, side = seg & 1;
     const int t0 = (frame * L.np + (side ? L.n1p : 0)) / MLP0_BN;
     const int nt = (side ? L.n2p : L.n1p) / MLP0_BN;
     const int n = side ? L.n2 : L.n1;
+    const int per = (nt + 15) / 16;
+    const int tb = part * per, te = min(nt, tb + per);
     double s = 0.0, s2 = 0.0;
-    for (int t = 0; t < nt; ++t) {
+#pragma unroll 8
+    for (int t = tb; t < te; ++t) {
         s += (double)statpart[((size_t)(t0 + t) * 2 + 0) * 512 + row];
         s2 += (double)statpart[((size_t)(t0 + t) * 2 + 1) * 512 + row];
     }
-    const double mean = s / n;
-    double var = s2 / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[((size_t)seg * 2 + 0) * 512 + row] = (float)mean;
-    stats[((size_t)seg * 2 + 1) * 512 + row] = (float)(1.0 / sqrt(var + 1e-5));
+    red[0][part][rl] = s;
+    red[1][part][rl] = s2;
+    __syncthreads();
+    if (part == 0) {
+        s = red[0][0][rl];
+        s2 = red[1][0][rl];
+#pragma unroll
+        for (int p = 1; p < 16; ++p) {
+            s += red[0][p][rl];
+            s2 += red[1][p][rl];
+        }
+        const double mean = s / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[((size_t)seg * 2 + 0) * 512 + row] = (float)mean;
+        stats[((size_t)seg * 2 + 1) * 512 + row] = (float)(1.0 / sqrt(var + 1e-5));
+    }
 }
 
 // =====================================================================================================
@@ -241,20 +278,23 @@ __global__ __launch_bounds__(256) void stat_final_kernel(const float* __restrict
 //     epilogue:  Z += W3 relu((u - mean) * rstd) + b3      (GATs_SuperGlue.py:126-128, :59,64)
 // =====================================================================================================
 using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;
+using Mlp3TileTall = GemmTile<128, 64, 2, 2, false>;
+using Mlp3TileWide = GemmTile<64, 128, 1, 4, false>;
 
+template <class T>
 __global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
                                                    const float* __restrict__ U, const float* __restrict__ stats,
                                                    float* __restrict__ Z, ColLayout L) {
-    using T = Mlp3Tile;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int rt, ct;
     const int NT = L.ld / T::BN;
-    if (!xcd_tile_map(4, NT, rt, ct)) return;
+    constexpr int MT = 256 / T::BM;
+    if (!xcd_tile_map(MT, NT, rt, ct)) return;
     const int c0 = ct * T::BN, ld = L.ld;
-    const TileSeg ts = tile_seg(L, c0, T::BN);
+    const TileSeg ts = tile_seg(L, c0, T::BN);  // segments start on multiples of 128: a tile never straddles two
     const float* mean = stats + ((size_t)ts.seg * 2 + 0) * 512;
     const float* rstd = stats + ((size_t)ts.seg * 2 + 1) * 512;
-    const float* A = W3 + (size_t)rt * 64 * 512;
+    const float* A = W3 + (size_t)rt * T::BM * 512;
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     gemm_mainloop<T>(
@@ -273,11 +313,15 @@ __global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ W3,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = rt * 64 + wm * 32 + mfma_row(r, half);
-        float* p = Z + (size_t)row * ld + c0 + wn * 32 + l31;
-        *p = *p + (acc[0][0][r] + b3[row]);
-    }
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * T::BM + (wm * T::TM + tm) * 32 + mfma_row(r, half);
+                float* p = Z + (size_t)row * ld + c0 + (wn * T::TN + tn) * 32 + l31;
+                *p = *p + (acc[tm][tn][r] + b3[row]);
+            }
 }
 
 // =====================================================================================================
@@ -441,7 +485,7 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hip
     const int NT = w.L.ld / QkvTile::BN;
     GATSSPG_LAUNCH(hk, KID_QKV_KV, s, qkv_kv_kernel, dim3(xcd_grid(6, NT)), dim3(256), smem_bytes<QkvTile>(), s, Wqkv, bqkv,
                    w.Z, w.Q, w.kvpart, w.L);
-    GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3((KVP + 255) / 256, w.nseg * H), dim3(256), 0, s, w.kvpart,
+    GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3(KVP / 64, w.nseg * H), dim3(1024), 0, s, w.kvpart,
                    w.kvfin, w.L);
 }
 
@@ -451,14 +495,36 @@ void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook
                    w.MSG, w.L, cross);
 }
 
+// tile selection: GATSSPG_MLP0_TILE / GATSSPG_MLP3_TILE (tuning knobs, read once)
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <class T>
+static void launch_mlp0_t(const float* W0, const float* b0, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    static const bool once = (allow_big_lds(mlp0_kernel<T>, smem_bytes<T>()), true);
+    (void)once;
+    const int NT = w.L.ld / T::BN;
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, mlp0_kernel<T>, dim3(xcd_grid(512 / T::BM, NT)), dim3(256), smem_bytes<T>(), s, W0, b0,
+                   w.Z, w.MSG, w.U, w.statpart, w.L);
+}
+template <class T>
+static void launch_mlp3_t(const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    const int NT = w.L.ld / T::BN;
+    GATSSPG_LAUNCH(hk, KID_MLP3, s, mlp3_kernel<T>, dim3(xcd_grid(256 / T::BM, NT)), dim3(256), smem_bytes<T>(), s, W3, b3,
+                   w.U, w.stats, w.Z, w.L);
+}
+
 void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const Workspace& w, hipStream_t s,
                 ProfileHook* hk) {
-    const int NT = w.L.ld / Mlp0Tile::BN;
-    GATSSPG_LAUNCH(hk, KID_MLP0, s, mlp0_kernel, dim3(xcd_grid(4, NT)), dim3(256), smem_bytes<Mlp0Tile>(), s, W0, b0, w.Z,
-                   w.MSG, w.U, w.statpart, w.L);
-    GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 2), dim3(256), 0, s, w.statpart, w.stats, w.L);
-    GATSSPG_LAUNCH(hk, KID_MLP3, s, mlp3_kernel, dim3(xcd_grid(4, NT)), dim3(256), smem_bytes<Mlp3Tile>(), s, W3, b3, w.U,
-                   w.stats, w.Z, w.L);
+    static const int t0 = env_int("GATSSPG_MLP0_TILE", 0), t3 = env_int("GATSSPG_MLP3_TILE", 0);
+    if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
+    else launch_mlp0_t<Mlp0Tile>(W0, b0, w, s, hk);
+    GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
+    if (t3 == 1) launch_mlp3_t<Mlp3TileTall>(W3, b3, w, s, hk);
+    else if (t3 == 2) launch_mlp3_t<Mlp3TileWide>(W3, b3, w, s, hk);
+    else launch_mlp3_t<Mlp3Tile>(W3, b3, w, s, hk);
 }
 
 void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk) {

@@ -255,21 +255,31 @@ void launch_gats(const float* u1, const float* u2, const float* leaves, int num_
 // ------------------------------------------------------------------------------------------------------
 // dual softmax finalisation + matching     (GATs_SuperGlue.py:218-237)
 // ------------------------------------------------------------------------------------------------------
-// row sums (over n2) and column sums (over n1) of E from the score kernel's per-tile partials
-__global__ __launch_bounds__(256) void softmax_sums_kernel(const float* __restrict__ rowpart,
-                                                           const float* __restrict__ colpart, float* __restrict__ rs,
-                                                           float* __restrict__ cs, ColLayout L, int nct, int nrt) {
-    const int f = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < L.n1p) {
-        float s = 0.f;
-        for (int t = 0; t < nct; ++t) s += rowpart[((size_t)f * nct + t) * L.n1p + idx];
-        rs[(size_t)f * L.n1p + idx] = s;
-    } else if (idx < L.n1p + L.n2p) {
-        const int j = idx - L.n1p;
-        float s = 0.f;
-        for (int t = 0; t < nrt; ++t) s += colpart[((size_t)f * nrt + t) * L.n2p + j];
-        cs[(size_t)f * L.n2p + j] = s;
+// row sums (over n2) and column sums (over n1) of E from the score kernel's per-tile partials.
+// 1024 threads = 64 outputs x 16 partial-ranges; ranges are summed in order and combined in order.
+__global__ __launch_bounds__(1024) void softmax_sums_kernel(const float* __restrict__ rowpart,
+                                                            const float* __restrict__ colpart, float* __restrict__ rs,
+                                                            float* __restrict__ cs, ColLayout L, int nct, int nrt) {
+    __shared__ float red[16][64];
+    const int f = blockIdx.y, el = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int nrb = L.n1p / 64;
+    const bool rows = (int)blockIdx.x < nrb;
+    const int idx = (rows ? blockIdx.x : blockIdx.x - nrb) * 64 + el;
+    const int T = rows ? nct : nrt;
+    const size_t stride = rows ? L.n1p : L.n2p;
+    const float* src = (rows ? rowpart : colpart) + (size_t)f * T * stride + idx;
+    const int per = (T + 15) / 16;
+    const int tb = part * per, te = min(T, tb + per);
+    float s = 0.f;
+#pragma unroll 8
+    for (int t = tb; t < te; ++t) s += src[(size_t)t * stride];
+    red[part][el] = s;
+    __syncthreads();
+    if (part == 0) {
+        float tot = red[0][el];
+#pragma unroll
+        for (int p = 1; p < 16; ++p) tot += red[p][el];
+        (rows ? rs : cs)[(size_t)f * stride + idx] = tot;
     }
 }
 
@@ -283,6 +293,9 @@ __device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int o
 // conf = softmax(S, dim=1) * softmax(S, dim=2) = (E / colsum) * (E / rowsum), in place over E;
 // per 16-row strip the column (max, first arg-max row), per 1024-column chunk the row (max, first
 // arg-max column).  torch.max on CPU breaks ties with the first index; so do we.
+// VEC: n2 % 4 == 0 -> each thread owns 4 consecutive columns (16-byte accesses); otherwise columns
+// tid + 256 k.  Rows are processed 4 at a time so that 4 loads per thread are in flight.
+template <bool VEC>
 __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ conf, const float* __restrict__ rs,
                                                             const float* __restrict__ cs, float* __restrict__ rmax_v,
                                                             int* __restrict__ rmax_i, float* __restrict__ cmax_v,
@@ -293,40 +306,69 @@ __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = st * CF_ROWS, j0 = chk * CF_COLS;
     float* cf = conf + (size_t)f * L.n1 * L.n2;
+    int jc[4];
     float csj[4], cmv[4];
     int cmi[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int j = j0 + tid + 256 * k;
-        csj[k] = j < L.n2 ? cs[(size_t)f * L.n2p + j] : 1.f;
+        jc[k] = VEC ? j0 + 4 * tid + k : j0 + tid + 256 * k;
+        csj[k] = jc[k] < L.n2 ? cs[(size_t)f * L.n2p + jc[k]] : 1.f;
         cmv[k] = -INFINITY;
         cmi[k] = 0;
     }
     const int nrows = min(CF_ROWS, L.n1 - i0);
-    for (int r = 0; r < nrows; ++r) {
-        const int i = i0 + r;
-        const float rsi = rs[(size_t)f * L.n1p + i];
-        float rv = -INFINITY;
-        int ri = 0x7fffffff;
+    for (int r0 = 0; r0 < nrows; r0 += 4) {
+        float e[4][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = j0 + tid + 256 * k;
-            if (j < L.n2) {
-                const size_t a = (size_t)i * L.n2 + j;
-                const float e = cf[a];
-                const float c = (e / csj[k]) * (e / rsi);
-                cf[a] = c;
-                if (c > cmv[k]) { cmv[k] = c; cmi[k] = i; }
-                if (c > rv) { rv = c; ri = j; }
+        for (int u = 0; u < 4; ++u) {
+            const size_t base = (size_t)(i0 + r0 + u) * L.n2;
+            if (r0 + u < nrows) {
+                if (VEC) {
+                    if (jc[0] < L.n2) {
+                        const float4 x = *reinterpret_cast<const float4*>(cf + base + jc[0]);
+                        e[u][0] = x.x; e[u][1] = x.y; e[u][2] = x.z; e[u][3] = x.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (jc[k] < L.n2) e[u][k] = cf[base + jc[k]];
+                }
             }
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float ov = __shfl_xor(rv, o);
-            const int oi = __shfl_xor(ri, o);
-            argmax_combine(rv, ri, ov, oi);
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u;
+            if (r < nrows) {  // uniform over the block
+                const int i = i0 + r;
+                const size_t base = (size_t)i * L.n2;
+                const float rsi = rs[(size_t)f * L.n1p + i];
+                float rv = -INFINITY;
+                int ri = 0x7fffffff;
+                float c[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (jc[k] < L.n2) {
+                        c[k] = (e[u][k] / csj[k]) * (e[u][k] / rsi);
+                        if (c[k] > cmv[k]) { cmv[k] = c[k]; cmi[k] = i; }
+                        if (c[k] > rv) { rv = c[k]; ri = jc[k]; }
+                    }
+                }
+                if (VEC) {
+                    if (jc[0] < L.n2) *reinterpret_cast<float4*>(cf + base + jc[0]) = make_float4(c[0], c[1], c[2], c[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (jc[k] < L.n2) cf[base + jc[k]] = c[k];
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const float ov = __shfl_xor(rv, o);
+                    const int oi = __shfl_xor(ri, o);
+                    argmax_combine(rv, ri, ov, oi);
+                }
+                if (lane == 0) { wv[r][wave] = rv; wi[r][wave] = ri; }
+            }
         }
-        if (lane == 0) { wv[r][wave] = rv; wi[r][wave] = ri; }
     }
     __syncthreads();
     if (tid < nrows) {
@@ -338,39 +380,58 @@ __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ 
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int j = j0 + tid + 256 * k;
-        if (j < L.n2) {
-            cmax_v[((size_t)f * nst + st) * L.n2p + j] = cmv[k];
-            cmax_i[((size_t)f * nst + st) * L.n2p + j] = cmi[k];
+        if (jc[k] < L.n2) {
+            cmax_v[((size_t)f * nst + st) * L.n2p + jc[k]] = cmv[k];
+            cmax_i[((size_t)f * nst + st) * L.n2p + jc[k]] = cmi[k];
         }
     }
 }
 
 // max0 / indices0 (per query, over n2) and indices1 (per 3D point, over n1)   GATs_SuperGlue.py:220-221
-__global__ __launch_bounds__(256) void match_reduce_kernel(const float* __restrict__ rmax_v, const int* __restrict__ rmax_i,
-                                                           const float* __restrict__ cmax_v, const int* __restrict__ cmax_i,
-                                                           float* __restrict__ max0, int* __restrict__ idx0,
-                                                           int* __restrict__ idx1, ColLayout L, int nch, int nst) {
-    const int f = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < L.n1) {
-        float v = -INFINITY;
-        int a = 0;
-        for (int c = 0; c < nch; ++c) {  // chunks in increasing column order: strict > keeps the first index
-            const float cv = rmax_v[((size_t)f * nch + c) * L.n1p + idx];
-            if (cv > v) { v = cv; a = rmax_i[((size_t)f * nch + c) * L.n1p + idx]; }
+// 64 outputs x 16 partial-ranges per block; partials are ordered by increasing index, ranges are
+// scanned and combined in order with a strict '>' so the first arg-max wins.
+__global__ __launch_bounds__(1024) void match_reduce_kernel(const float* __restrict__ rmax_v, const int* __restrict__ rmax_i,
+                                                            const float* __restrict__ cmax_v, const int* __restrict__ cmax_i,
+                                                            float* __restrict__ max0, int* __restrict__ idx0,
+                                                            int* __restrict__ idx1, ColLayout L, int nch, int nst) {
+    __shared__ float rv[16][64];
+    __shared__ int ri[16][64];
+    const int f = blockIdx.y, el = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int nrb = L.n1p / 64;
+    const bool rows = (int)blockIdx.x < nrb;
+    const int idx = (rows ? blockIdx.x : blockIdx.x - nrb) * 64 + el;
+    const int T = rows ? nch : nst;
+    const size_t stride = rows ? L.n1p : L.n2p;
+    const float* pv = (rows ? rmax_v : cmax_v) + (size_t)f * T * stride + idx;
+    const int* pi = (rows ? rmax_i : cmax_i) + (size_t)f * T * stride + idx;
+    const bool live = idx < (rows ? L.n1 : L.n2);
+    const int per = (T + 15) / 16;
+    const int tb = part * per, te = min(T, tb + per);
+    float v = -INFINITY;
+    int a = 0;
+    if (live) {
+#pragma unroll 4
+        for (int t = tb; t < te; ++t) {
+            const float cv = pv[(size_t)t * stride];
+            const int ci = pi[(size_t)t * stride];
+            if (cv > v) { v = cv; a = ci; }
         }
-        max0[(size_t)f * L.n1p + idx] = v;
-        idx0[(size_t)f * L.n1p + idx] = a;
-    } else if (idx >= L.n1p && idx - L.n1p < L.n2) {
-        const int j = idx - L.n1p;
-        float v = -INFINITY;
-        int a = 0;
-        for (int s = 0; s < nst; ++s) {
-            const float cv = cmax_v[((size_t)f * nst + s) * L.n2p + j];
-            if (cv > v) { v = cv; a = cmax_i[((size_t)f * nst + s) * L.n2p + j]; }
+    }
+    rv[part][el] = v;
+    ri[part][el] = a;
+    __syncthreads();
+    if (part == 0 && live) {
+        v = rv[0][el];
+        a = ri[0][el];
+#pragma unroll
+        for (int p = 1; p < 16; ++p)
+            if (rv[p][el] > v) { v = rv[p][el]; a = ri[p][el]; }
+        if (rows) {
+            max0[(size_t)f * L.n1p + idx] = v;
+            idx0[(size_t)f * L.n1p + idx] = a;
+        } else {
+            idx1[(size_t)f * L.n2p + idx] = a;
         }
-        idx1[(size_t)f * L.n2p + j] = a;
     }
 }
 
@@ -408,12 +469,18 @@ void launch_dual_softmax_match(const Workspace& w, float* conf, float thr, int64
                                float* mscores0, float* mscores1, hipStream_t s, ProfileHook* hk) {
     const ColLayout& L = w.L;
     const dim3 g1((L.n1p + L.n2p + 255) / 256, L.b);
-    GATSSPG_LAUNCH(hk, KID_SOFTMAX_SUMS, s, softmax_sums_kernel, g1, dim3(256), 0, s, w.rowpart, w.colpart, w.rs, w.cs, L,
+    const dim3 g64((L.n1p + L.n2p) / 64, L.b);
+    GATSSPG_LAUNCH(hk, KID_SOFTMAX_SUMS, s, softmax_sums_kernel, g64, dim3(1024), 0, s, w.rowpart, w.colpart, w.rs, w.cs, L,
                    w.sc_nct, w.sc_nrt);
-    GATSSPG_LAUNCH(hk, KID_CONF_FINALIZE, s, conf_finalize_kernel, dim3(w.cf_nch, w.cf_nst, L.b), dim3(256), 0, s, conf, w.rs,
-                   w.cs, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, L, w.cf_nch, w.cf_nst);
-    GATSSPG_LAUNCH(hk, KID_MATCH_REDUCE, s, match_reduce_kernel, g1, dim3(256), 0, s, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i,
-                   w.max0, w.idx0, w.idx1, L, w.cf_nch, w.cf_nst);
+    if ((L.n2 & 3) == 0 && (reinterpret_cast<uintptr_t>(conf) & 15) == 0) {
+        GATSSPG_LAUNCH(hk, KID_CONF_FINALIZE, s, conf_finalize_kernel<true>, dim3(w.cf_nch, w.cf_nst, L.b), dim3(256), 0, s,
+                       conf, w.rs, w.cs, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, L, w.cf_nch, w.cf_nst);
+    } else {
+        GATSSPG_LAUNCH(hk, KID_CONF_FINALIZE, s, conf_finalize_kernel<false>, dim3(w.cf_nch, w.cf_nst, L.b), dim3(256), 0, s,
+                       conf, w.rs, w.cs, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, L, w.cf_nch, w.cf_nst);
+    }
+    GATSSPG_LAUNCH(hk, KID_MATCH_REDUCE, s, match_reduce_kernel, g64, dim3(1024), 0, s, w.rmax_v, w.rmax_i, w.cmax_v,
+                   w.cmax_i, w.max0, w.idx0, w.idx1, L, w.cf_nch, w.cf_nst);
     GATSSPG_LAUNCH(hk, KID_MATCH_TAIL, s, match_tail_kernel, g1, dim3(256), 0, s, w.max0, w.idx0, w.idx1, thr, matches0,
                    matches1, mscores0, mscores1, L);
 }
