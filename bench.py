@@ -6,8 +6,11 @@
 
 One "step" = one GATsSuperGlue.forward-equivalent (descriptors already resident in HBM ->
 pred + conf_matrix in HBM) on BASELINE.json configs[1]: synthetic unit-norm descriptors,
-N_2D=1000, N_3D=7000, d=256, num_leaf=8, batch 1, fp32, random-init weights.  With N>1 every rank
-runs its own K frames (weak scaling, no data-path collective); value = all frames / max-over-ranks time.
+N_2D=1000, N_3D=7000, d=256, num_leaf=8, batch 1, fp32, random-init weights.  Query frames are
+independent units, so each GPU keeps --streams frames in flight (one HIP stream, workspace and output
+set each); the K timed steps are dealt round-robin to those slots.  With N>1 every rank runs its own
+K frames (weak scaling, no data-path collective); value = all frames / max-over-ranks time.  The
+one-frame-at-a-time latency is reported next to it in config.
 
 The JSON line also carries
   roofline     : the dominant kernel (mlp0: the folded merge+mlp.0 fp32-MFMA GEMM) timed live with HIP
@@ -47,37 +50,52 @@ def kernel_flops(name, n1, n2):
     return {"mlp0": 2 * 512 * 512 * n,          # [512x512] x [x ; msg]  (merge folded in: algorithmic 10 d^2 n)
             "qkv_kv": 2 * 768 * 256 * n + 2 * 256 * 64 * n,
             "mlp3": 2 * 256 * 512 * n,
-            "score_exp": 2 * n1 * n2 * 256}[name]
+            "score_exp": 2 * n1 * n2 * 256, "final_proj_norm": 2 * 256 * 256 * n, "attn_apply": 2 * 256 * 64 * n}.get(name, 1)
 
 
-class Runner:
-    """Everything pre-allocated; step() is a single C-ABI call on the current stream."""
+class Weights:
+    """Random-init GATsSPG weights packed once on the device (shared by every in-flight frame)."""
 
-    def __init__(self, device, b=1, n1=N1, n2=N2, n_query_frames=4):
-        self.device = device
-        self.b, self.n1, self.n2 = b, n1, n2
+    def __init__(self, device):
         sd = synthetic.make_state_dict(0)
         self.model = GATsSuperGlue(HP).eval()
         self.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
         self.model.to(device)
-        data = synthetic.make_inputs(b, n1, n2, NUM_LEAF, seed=1)
-        self.d3 = torch.from_numpy(data["descriptors3d_db"]).to(device)
-        self.d2db = torch.from_numpy(data["descriptors2d_db"]).to(device)
-        rs = np.random.RandomState(7)
-        q = rs.standard_normal((n_query_frames, b, D, n1)).astype(np.float32)
-        q /= np.linalg.norm(q, axis=2, keepdims=True)
-        self.queries = [torch.from_numpy(q[i]).to(device) for i in range(n_query_frames)]
-        eng = self.model.engine
-        self.lib = eng.lib
-        self.packed = eng.packed_weights(device)
-        self.ws = eng.workspace(b, n1, n2, NUM_LEAF, device)
-        self.flags = eng.flags()
+        self.engine = self.model.engine
+        self.packed = self.engine.packed_weights(device)
+        self.flags = self.engine.flags()
+
+
+class Runner:
+    """One in-flight frame slot: its own HIP stream, workspace and output buffers, everything
+    pre-allocated; step() is a single C-ABI call that enqueues one forward on the slot's stream."""
+
+    def __init__(self, device, weights, shared_inputs=None, b=1, n1=N1, n2=N2, n_query_frames=4, own_stream=False):
+        self.device = device
+        self.b, self.n1, self.n2 = b, n1, n2
+        if shared_inputs is None:
+            # the 3D database (descriptors3d_db + its leaves) is per object and constant across query
+            # frames (inference.py:113-130); query descriptors rotate over a small pool of frames
+            data = synthetic.make_inputs(b, n1, n2, NUM_LEAF, seed=1)
+            d3 = torch.from_numpy(data["descriptors3d_db"]).to(device)
+            d2db = torch.from_numpy(data["descriptors2d_db"]).to(device)
+            rs = np.random.RandomState(7)
+            q = rs.standard_normal((n_query_frames, b, D, n1)).astype(np.float32)
+            q /= np.linalg.norm(q, axis=2, keepdims=True)
+            shared_inputs = (d3, d2db, [torch.from_numpy(q[i]).to(device) for i in range(n_query_frames)])
+        self.shared_inputs = shared_inputs
+        self.d3, self.d2db, self.queries = shared_inputs
+        self.lib = weights.engine.lib
+        self.packed = weights.packed
+        self.flags = weights.flags
+        nbytes = self.lib.gatsspg_workspace_bytes(b, n1, n2, NUM_LEAF)
+        self.ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
         self.conf = torch.empty(b, n1, n2, device=device)
         self.m0 = torch.empty(b, n1, device=device, dtype=torch.int64)
         self.m1 = torch.empty(b, n2, device=device, dtype=torch.int64)
         self.s0 = torch.empty(b, n1, device=device)
         self.s1 = torch.empty(b, n2, device=device)
-        self.stream = torch.cuda.current_stream(device)
+        self.stream = torch.cuda.Stream(device) if own_stream else torch.cuda.current_stream(device)
 
     def _common(self, i):
         q = self.queries[i % len(self.queries)]
@@ -122,8 +140,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=3, help="query frames kept in flight per GPU (one HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel", default=DOMINANT, choices=["mlp0", "qkv_kv", "mlp3", "score_exp"])
+    ap.add_argument("--kernel", default=DOMINANT, choices=list(_native.KERNEL_IDS))
     args = ap.parse_args()
 
     rank, local_rank, world = sharding.init_process_group()
@@ -135,27 +154,45 @@ def main():
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
-    runner = Runner(device)
-    K, W = args.steps, args.warmup
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    for e0, e1 in events:  # create the underlying hipEvent_t handles
-        e0.record(runner.stream)
-        e1.record(runner.stream)
+    weights = Weights(device)
+    K, W, S = args.steps, args.warmup, max(1, args.streams)
+    base = Runner(device, weights)
+    slots = [Runner(device, weights, base.shared_inputs, own_stream=True) for _ in range(S)]
+    torch.cuda.synchronize(device)
+
+    # ---- timed region: K steps, frame i on in-flight slot i % S (independent frames, no data-path collective)
     for i in range(W):
-        runner.step(i)
+        slots[i % S].step(i)
     torch.cuda.synchronize(device)
     sharding.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for i in range(K):
-        runner.step_profiled(i, args.kernel, events[i][0], events[i][1])
+        slots[i % S].step(i)
     torch.cuda.synchronize(device)
     sharding.barrier()
     elapsed = time.perf_counter() - t0
 
+    # ---- second pass, one frame at a time on one stream: frame latency, and the dominant kernel bracketed by
+    #      HIP events recorded on that stream around one of its launches in every step
+    runner = slots[0]
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    with torch.cuda.stream(runner.stream):
+        for e0, e1 in events:  # create the underlying hipEvent_t handles
+            e0.record(runner.stream)
+            e1.record(runner.stream)
+        for i in range(W):
+            runner.step(i)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for i in range(K):
+            runner.step_profiled(i, args.kernel, events[i][0], events[i][1])
+        torch.cuda.synchronize(device)
+        latency = (time.perf_counter() - t1) / K
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+
     per_rank = sharding.gather_metrics([K * runner.b, elapsed], device=device)  # the one (RCCL) collective
     value, seconds = sharding.aggregate_throughput(per_rank.cpu())
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
 
     if rank == 0:
         fl = kernel_flops(args.kernel, N1, N2)
@@ -167,13 +204,16 @@ def main():
             "config": {"workload": "BASELINE configs[1]: synthetic unit-norm desc_2d/desc_3d, N_2D=1000 N_3D=7000 d=256 "
                                    "num_leaf=8, batch=1 per step, fp32, random-init GATsSPG weights (12 GNN layers)",
                        "n_2d": N1, "n_3d": N2, "num_leaf": NUM_LEAF, "batch": runner.b, "frames_per_gpu": K,
+                       "frames_in_flight_per_gpu": S, "single_frame_latency_ms": round(latency * 1e3, 4),
+                       "single_stream_frames_per_sec": round(1.0 / latency, 2),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
                        "algorithmic_gflop_per_frame": round(f_alg(N1, N2, NUM_LEAF) / 1e9, 2),
                        "end_to_end_f32_mfma_frac": round(f_alg(N1, N2, NUM_LEAF) * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "kernel": args.kernel + "_kernel", "achieved": round(achieved, 2),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "traffic": None, "kernel_ms": round(kern_ms, 5), "flops_per_launch": fl,
-                         "how": f"hipEvent pair around launch #0 of {args.kernel}_kernel in each of the {K} timed steps"},
+                         "how": f"hipEvent pair on the compute stream around launch #0 of {args.kernel}_kernel in each of {K} "
+                                f"steps of a one-frame-at-a-time pass (the throughput pass overlaps {S} frames)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256) void qkv_kv_kernel(const float* __restrict__ W
     zero_acc(acc);
     gemm_mainloop<T>(
         acc, smem, D / BK,
-        [&](int kt, int r, int c) { return *reinterpret_cast<const float4*>(A + (size_t)r * D + kt * BK + c); },
-        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(Z + (size_t)(kt * BK + k) * ld + c0 + c); });
+        [&](int kt, int r, int c) { return ldg4(A + (size_t)r * D + kt * BK + c); },
+        [&](int kt, int k, int c) { return ldg4(Z + (size_t)(kt * BK + k) * ld + c0 + c); });
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
     zero_acc(acc);
     gemm_mainloop<T>(
         acc, smem, DH / BK,
-        [&](int kt, int r, int c) { return *reinterpret_cast<const float4*>(KV + r * DH + kt * BK + c); },
-        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(Qh + (size_t)(kt * BK + k) * ld + c0 + c); });
+        [&](int kt, int r, int c) { return ldg4(KV + r * DH + kt * BK + c); },
+        [&](int kt, int k, int c) { return ldg4(Qh + (size_t)(kt * BK + k) * ld + c0 + c); });
     if (tid < 64) zs[tid] = 1.f / (((zpart[0][tid] + zpart[1][tid]) + (zpart[2][tid] + zpart[3][tid])) + 1e-6f);
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
@@ -198,10 +198,10 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
     zero_acc(acc);
     gemm_mainloop<T>(
         acc, smem, 512 / BK,
-        [&](int kt, int r, int c) { return *reinterpret_cast<const float4*>(A + (size_t)r * 512 + kt * BK + c); },
+        [&](int kt, int r, int c) { return ldg4(A + (size_t)r * 512 + kt * BK + c); },
         [&](int kt, int k, int c) {
             const float* src = kt < 8 ? Z + (size_t)(kt * BK + k) * ld : MSG + (size_t)((kt - 8) * BK + k) * ld;
-            return *reinterpret_cast<const float4*>(src + c0 + c);
+            return ldg4(src + c0 + c);
         });
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
@@ -281,7 +281,7 @@ using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;
 using Mlp3TileTall = GemmTile<128, 64, 2, 2, false>;
 using Mlp3TileWide = GemmTile<64, 128, 1, 4, false>;
 
-template <class T>
+template <class T, int ABL = 0>
 __global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
                                                    const float* __restrict__ U, const float* __restrict__ stats,
                                                    float* __restrict__ Z, ColLayout L) {
@@ -297,19 +297,14 @@ __global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ W3,
     const float* A = W3 + (size_t)rt * T::BM * 512;
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
-    gemm_mainloop<T>(
-        acc, smem, 512 / BK,
-        [&](int kt, int r, int c) { return *reinterpret_cast<const float4*>(A + (size_t)r * 512 + kt * BK + c); },
-        [&](int kt, int k, int c) {
-            const int kr = kt * BK + k;
-            float4 v = *reinterpret_cast<const float4*>(U + (size_t)kr * ld + c0 + c);
-            const float m = mean[kr], s = rstd[kr];
-            v.x = fmaxf((v.x - m) * s, 0.f);
-            v.y = fmaxf((v.y - m) * s, 0.f);
-            v.z = fmaxf((v.z - m) * s, 0.f);
-            v.w = fmaxf((v.w - m) * s, 0.f);
-            return v;
-        });
+    auto al = [&](int kt, int r, int c) { return ldg4(A + (size_t)r * 512 + kt * BK + c); };
+    auto bl = [&](int kt, int k, int c) { return ldg4(U + (size_t)(kt * BK + k) * ld + c0 + c); };
+    auto ba = [&](int kt, int k) { return make_float2(mean[kt * BK + k], rstd[kt * BK + k]); };
+    auto bx = [](vf4& v, float2 ms) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf((v[q] - ms.x) * ms.y, 0.f);
+    };
+    gemm_mainloop<T, decltype(al), decltype(bl), decltype(ba), decltype(bx), ABL>(acc, smem, 512 / BK, al, bl, ba, bx);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -343,8 +338,8 @@ __global__ __launch_bounds__(256) void final_proj_norm_kernel(const float* __res
     zero_acc(acc);
     gemm_mainloop<T>(
         acc, smem, D / BK,
-        [&](int kt, int r, int c) { return *reinterpret_cast<const float4*>(Wf + (size_t)r * D + kt * BK + c); },
-        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(Z + (size_t)(kt * BK + k) * ld + c0 + c); });
+        [&](int kt, int r, int c) { return ldg4(Wf + (size_t)r * D + kt * BK + c); },
+        [&](int kt, int k, int c) { return ldg4(Z + (size_t)(kt * BK + k) * ld + c0 + c); });
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     float ss = 0.f;
@@ -396,8 +391,8 @@ __global__ __launch_bounds__(256) void score_exp_kernel(const float* __restrict_
     zero_acc(acc);
     gemm_mainloop<T>(
         acc, smem, D / BK,
-        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(Ap + (size_t)(kt * BK + k) * ld + c); },
-        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(Bp + (size_t)(kt * BK + k) * ld + c); });
+        [&](int kt, int k, int c) { return ldg4(Ap + (size_t)(kt * BK + k) * ld + c); },
+        [&](int kt, int k, int c) { return ldg4(Bp + (size_t)(kt * BK + k) * ld + c); });
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
     constexpr int TS = T::BN + 1;
@@ -453,8 +448,8 @@ __global__ __launch_bounds__(256) void gats_wlt_kernel(const float* __restrict__
     zero_acc(acc);
     gemm_mainloop<T>(
         acc, smem, D / BK,
-        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(W + (size_t)(kt * BK + k) * D + rt * 64 + c); },
-        [&](int kt, int k, int c) { return *reinterpret_cast<const float4*>(P + (size_t)(kt * BK + k) * ld + c0 + c); });
+        [&](int kt, int k, int c) { return ldg4(W + (size_t)(kt * BK + k) * D + rt * 64 + c); },
+        [&](int kt, int k, int c) { return ldg4(P + (size_t)(kt * BK + k) * ld + c0 + c); });
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -473,26 +468,45 @@ __global__ __launch_bounds__(256) void gats_wlt_kernel(const float* __restrict__
 template <class T>
 constexpr size_t smem_bytes() { return sizeof(float) * T::SMEM_FLOATS; }
 
+// Residency shaping: the hardware workgroup dispatcher packs as many workgroups onto a CU as its
+// resources admit, so a grid of ~2 workgroups per CU whose kernel could fit 4 ends up with some CUs
+// holding 4 (taking 2x as long) and others idle.  Requesting 160 KiB / ceil(grid / 256) of LDS per
+// workgroup caps the residency at the balanced value.  Measured: no gain at one frame in flight, and it
+// blocks co-residency with other frames' kernels, so it is OFF unless GATSSPG_LDS_SHAPING=1.
+static size_t shaped_lds(size_t needed, int nblocks) {
+    static const bool on = [] { const char* v = getenv("GATSSPG_LDS_SHAPING"); return v && atoi(v) != 0; }();
+    if (!on) return needed;
+    const int per_cu = (nblocks + 255) / 256;
+    size_t bytes = ((size_t)160 * 1024 / (per_cu < 1 ? 1 : per_cu) - 2048) & ~(size_t)1023;
+    return bytes > needed ? bytes : needed;
+}
+
 // kernels whose dynamic LDS exceeds the 64 KiB default need the limit raised once per process
 template <class K>
-void allow_big_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)bytes);
+void allow_big_lds(K kernel, size_t = 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024 - 2048);
 }
+#define GATSSPG_BIG_LDS_ONCE(kernel)                                  \
+    do {                                                              \
+        static const bool once_ = (allow_big_lds(kernel), true);      \
+        (void)once_;                                                  \
+    } while (0)
 
 void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     const int NT = w.L.ld / QkvTile::BN;
-    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, qkv_kv_kernel, dim3(xcd_grid(6, NT)), dim3(256), smem_bytes<QkvTile>(), s, Wqkv, bqkv,
-                   w.Z, w.Q, w.kvpart, w.L);
+    GATSSPG_BIG_LDS_ONCE(qkv_kv_kernel);
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, qkv_kv_kernel, dim3(xcd_grid(6, NT)), dim3(256),
+                   shaped_lds(smem_bytes<QkvTile>(), 6 * NT), s, Wqkv, bqkv, w.Z, w.Q, w.kvpart, w.L);
     GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3(KVP / 64, w.nseg * H), dim3(1024), 0, s, w.kvpart,
                    w.kvfin, w.L);
 }
 
 void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook* hk) {
     const int NT = w.L.ld / ApplyTile::BN;
-    GATSSPG_LAUNCH(hk, KID_ATTN_APPLY, s, attn_apply_kernel, dim3(NT * H), dim3(256), smem_bytes<ApplyTile>(), s, w.kvfin, w.Q,
-                   w.MSG, w.L, cross);
+    GATSSPG_BIG_LDS_ONCE(attn_apply_kernel);
+    GATSSPG_LAUNCH(hk, KID_ATTN_APPLY, s, attn_apply_kernel, dim3(NT * H), dim3(256),
+                   shaped_lds(smem_bytes<ApplyTile>(), NT * H), s, w.kvfin, w.Q, w.MSG, w.L, cross);
 }
 
 // tile selection: GATSSPG_MLP0_TILE / GATSSPG_MLP3_TILE (tuning knobs, read once)
@@ -503,17 +517,18 @@ static int env_int(const char* name, int dflt) {
 
 template <class T>
 static void launch_mlp0_t(const float* W0, const float* b0, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    static const bool once = (allow_big_lds(mlp0_kernel<T>, smem_bytes<T>()), true);
-    (void)once;
+    GATSSPG_BIG_LDS_ONCE(mlp0_kernel<T>);
     const int NT = w.L.ld / T::BN;
-    GATSSPG_LAUNCH(hk, KID_MLP0, s, mlp0_kernel<T>, dim3(xcd_grid(512 / T::BM, NT)), dim3(256), smem_bytes<T>(), s, W0, b0,
-                   w.Z, w.MSG, w.U, w.statpart, w.L);
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, mlp0_kernel<T>, dim3(xcd_grid(512 / T::BM, NT)), dim3(256),
+                   shaped_lds(smem_bytes<T>(), 512 / T::BM * NT), s, W0, b0, w.Z, w.MSG, w.U, w.statpart, w.L);
 }
-template <class T>
+template <class T, int ABL = 0>
 static void launch_mlp3_t(const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    auto kern = mlp3_kernel<T, ABL>;
+    GATSSPG_BIG_LDS_ONCE(kern);
     const int NT = w.L.ld / T::BN;
-    GATSSPG_LAUNCH(hk, KID_MLP3, s, mlp3_kernel<T>, dim3(xcd_grid(256 / T::BM, NT)), dim3(256), smem_bytes<T>(), s, W3, b3,
-                   w.U, w.stats, w.Z, w.L);
+    GATSSPG_LAUNCH(hk, KID_MLP3, s, kern, dim3(xcd_grid(256 / T::BM, NT)), dim3(256),
+                   shaped_lds(smem_bytes<T>(), 256 / T::BM * NT), s, W3, b3, w.U, w.stats, w.Z, w.L);
 }
 
 void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const Workspace& w, hipStream_t s,
@@ -522,21 +537,25 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
     else launch_mlp0_t<Mlp0Tile>(W0, b0, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
-    if (t3 == 1) launch_mlp3_t<Mlp3TileTall>(W3, b3, w, s, hk);
+    if (t3 == 11) launch_mlp3_t<Mlp3Tile, 1>(W3, b3, w, s, hk);        // ablation: no global loads in the loop
+    else if (t3 == 12) launch_mlp3_t<Mlp3Tile, 2>(W3, b3, w, s, hk);   // ablation: no loads, no LDS writes
+    else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3>(W3, b3, w, s, hk);   // ablation: fixed cost only
+    else if (t3 == 1) launch_mlp3_t<Mlp3TileTall>(W3, b3, w, s, hk);
     else if (t3 == 2) launch_mlp3_t<Mlp3TileWide>(W3, b3, w, s, hk);
     else launch_mlp3_t<Mlp3Tile>(W3, b3, w, s, hk);
 }
 
 void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    static const bool once = (allow_big_lds(final_proj_norm_kernel, smem_bytes<FinalTile>()), true);
-    (void)once;
+    GATSSPG_BIG_LDS_ONCE(final_proj_norm_kernel);
     GATSSPG_LAUNCH(hk, KID_FINAL_PROJ, s, final_proj_norm_kernel, dim3(w.L.ld / FinalTile::BN), dim3(256),
                    smem_bytes<FinalTile>(), s, Wf, bf, w.Z, w.MD, w.L);
 }
 
 void launch_score_exp(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk) {
+    GATSSPG_BIG_LDS_ONCE(score_exp_kernel);
     GATSSPG_LAUNCH(hk, KID_SCORE_EXP, s, score_exp_kernel, dim3(xcd_grid(w.sc_nrt, w.sc_nct), w.L.b), dim3(256),
-                   smem_bytes<ScoreTile>(), s, w.MD, conf, w.rowpart, w.colpart, w.L, scale);
+                   shaped_lds(smem_bytes<ScoreTile>(), w.sc_nrt * w.sc_nct * w.L.b), s, w.MD, conf, w.rowpart, w.colpart,
+                   w.L, scale);
 }
 
 void launch_gats_wlt(const float* W, const float* P, const Workspace& w, int add_h, hipStream_t s, ProfileHook* hk) {

@@ -20,6 +20,10 @@
 namespace gatsspg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// staging registers use a first-class vector type: HIP's float4 is a struct, and a struct copy
+// global -> register -> LDS is forwarded by MemCpyOpt into a late global->LDS copy (load next to its use)
+typedef float vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ vf4 ldg4(const float* p) { return *reinterpret_cast<const vf4*>(p); }
 
 template <int BM_, int BN_, int WM_, int WN_, bool AKM_>
 struct GemmTile {
@@ -45,9 +49,22 @@ __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * 
 // aload(kt, r, c): float4 of the A slab kt.  row-major A: rows r of the tile, k offset c (0,4,..,28).
 //                  KM A: slab row k = r (0..31), tile column c (multiple of 4).
 // bload(kt, k, c): float4 of B slab kt, slab row k (0..31), tile column c (multiple of 4).
-template <class T, class ALoad, class BLoad>
+// baux(kt, k):     per-row float2 fetched together with the B slab (e.g. InstanceNorm mean / rstd);
+// bxform(v, aux):  applied to the B registers when they are written to LDS (after the MFMAs), so
+//                  the raw load has a whole slab of MFMA time to land.
+struct NoAux {
+    __device__ __forceinline__ float2 operator()(int, int) const { return make_float2(0.f, 0.f); }
+};
+struct NoXform {
+    __device__ __forceinline__ void operator()(vf4&, float2) const {}
+};
+
+// ABLATE (profiling only, wrong results): 1 = no global loads in the steady-state loop,
+//                                         2 = no global loads and no LDS writes (pure LDS-read + MFMA loop)
+//                                         3 = steady-state loop skipped (fixed cost: prologue + 1 slab + epilogue)
+template <class T, class ALoad, class BLoad, class BAux = NoAux, class BXform = NoXform, int ABLATE = 0>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ALoad aload,
-                                              BLoad bload) {
+                                              BLoad bload, BAux baux = BAux(), BXform bxform = BXform()) {
     constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -55,7 +72,8 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float
     const int wm = wave / T::WN, wn = wave % T::WN;
     const int half = lane >> 5, l31 = lane & 31;
 
-    float4 ra[T::A_VEC], rb[T::B_VEC];
+    vf4 ra[T::A_VEC], rb[T::B_VEC];
+    float2 rx[T::B_VEC];
 
     auto gload = [&](int kt) {
 #pragma unroll
@@ -71,6 +89,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float
         for (int p = 0; p < T::B_VEC; ++p) {
             const int idx = p * 256 + tid;
             rb[p] = bload(kt, idx / (BN / 4), (idx % (BN / 4)) * 4);
+            rx[p] = baux(kt, idx / (BN / 4));
         }
     };
     auto swrite = [&](float* stage) {
@@ -80,15 +99,17 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float
         for (int p = 0; p < T::A_VEC; ++p) {
             const int idx = p * 256 + tid;
             if constexpr (T::AKM) {
-                *reinterpret_cast<float4*>(As + (idx / (BM / 4)) * BM + (idx % (BM / 4)) * 4) = ra[p];
+                *reinterpret_cast<vf4*>(As + (idx / (BM / 4)) * BM + (idx % (BM / 4)) * 4) = ra[p];
             } else {
-                *reinterpret_cast<float4*>(As + (idx / (BK / 4)) * T::A_STRIDE + (idx % (BK / 4)) * 4) = ra[p];
+                *reinterpret_cast<vf4*>(As + (idx / (BK / 4)) * T::A_STRIDE + (idx % (BK / 4)) * 4) = ra[p];
             }
         }
 #pragma unroll
         for (int p = 0; p < T::B_VEC; ++p) {
             const int idx = p * 256 + tid;
-            *reinterpret_cast<float4*>(Bs + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4) = rb[p];
+            vf4 v = rb[p];
+            bxform(v, rx[p]);
+            *reinterpret_cast<vf4*>(Bs + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4) = v;
         }
     };
     auto compute = [&](const float* stage) {
@@ -102,12 +123,12 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float
                 for (int s = 0; s < 16; ++s)
                     a[tm][s] = As[(half * 16 + s) * BM + wm * TM * 32 + tm * 32 + l31];
             } else {
-                const float4* ap =
-                    reinterpret_cast<const float4*>(As + (wm * TM * 32 + tm * 32 + l31) * T::A_STRIDE + half * 16);
+                const vf4* ap =
+                    reinterpret_cast<const vf4*>(As + (wm * TM * 32 + tm * 32 + l31) * T::A_STRIDE + half * 16);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const float4 x = ap[v];
-                    a[tm][4 * v + 0] = x.x; a[tm][4 * v + 1] = x.y; a[tm][4 * v + 2] = x.z; a[tm][4 * v + 3] = x.w;
+                    const vf4 x = ap[v];
+                    a[tm][4 * v + 0] = x[0]; a[tm][4 * v + 1] = x[1]; a[tm][4 * v + 2] = x[2]; a[tm][4 * v + 3] = x[3];
                 }
             }
         }
@@ -127,15 +148,23 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float
     gload(0);
     swrite(smem);
     __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
+    // Steady state: branch-free body (the last slab is peeled) so that hipcc cannot sink the global
+    // loads into a conditional block next to their vmcnt wait; sched_barrier pins the issue order
+    // loads -> MFMAs -> LDS writes, i.e. the loads have the whole slab of MFMA time to land.
+    for (int kt = 0; kt + 1 < (ABLATE == 3 ? 1 : KT); ++kt) {
         float* cur = smem + (kt & 1) * T::STAGE_FLOATS;
         float* nxt = smem + ((kt + 1) & 1) * T::STAGE_FLOATS;
-        const bool more = kt + 1 < KT;
-        if (more) gload(kt + 1);
+        if constexpr (ABLATE == 0) gload(kt + 1);
+        asm volatile("" ::: "memory");  // SelectionDAG-level pin (sched_barrier alone is not a memory fence)
+        __builtin_amdgcn_sched_barrier(0);
         compute(cur);
-        if (more) swrite(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        if constexpr (ABLATE <= 1) swrite(nxt);
         __syncthreads();
     }
+    compute(smem + ((KT - 1) & 1) * T::STAGE_FLOATS);
+    __syncthreads();  // callers re-use the LDS for their epilogue
 }
 
 template <int TM, int TN>
