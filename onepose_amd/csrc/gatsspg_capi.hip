@@ -205,6 +205,9 @@ int gatsspg_forward_profiled(const float* packed, const float* desc2d_query, con
     return 0;
 }
 
+/* debug only (not part of the public header): per-workgroup timeline of mlp0_kernel, 8 u64 per workgroup */
+void gatsspg_debug_set_trace(void* buf) { g_trace = static_cast<unsigned long long*>(buf); }
+
 size_t gatsspg_kenc_scratch_bytes(int b, int n) { return (b < 1 || n < 1) ? 0 : kenc_scratch_bytes(b, n); }
 
 int gatsspg_keypoint_encoder(const gatsspg_kenc_weights* kw, const float* kpts, const float* scores, int b, int n,

@@ -32,9 +32,8 @@ __global__ __launch_bounds__(256) void qkv_kv_kernel(const float* __restrict__ W
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     gemm_mainloop<T>(
-        acc, smem, D / BK,
-        [&](int kt, int r, int c) { return ldg4(A + (size_t)r * D + kt * BK + c); },
-        [&](int kt, int k, int c) { return ldg4(Z + (size_t)(kt * BK + k) * ld + c0 + c); });
+        acc, smem, D / BK, [&](int kt) { return A + kt * BK; }, D,
+        [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
@@ -158,9 +157,8 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     gemm_mainloop<T>(
-        acc, smem, DH / BK,
-        [&](int kt, int r, int c) { return ldg4(KV + r * DH + kt * BK + c); },
-        [&](int kt, int k, int c) { return ldg4(Qh + (size_t)(kt * BK + k) * ld + c0 + c); });
+        acc, smem, DH / BK, [&](int kt) { return KV + kt * BK; }, DH,
+        [&](int kt) { return Qh + (size_t)kt * BK * ld + c0; }, ld);
     if (tid < 64) zs[tid] = 1.f / (((zpart[0][tid] + zpart[1][tid]) + (zpart[2][tid] + zpart[3][tid])) + 1e-6f);
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
@@ -183,11 +181,17 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
 using Mlp0Tile = GemmTile<128, MLP0_BN, 2, 2, false>;
 using Mlp0TileWide = GemmTile<256, MLP0_BN, 4, 1, false>;
 
-template <class T>
+// debug-only per-workgroup timeline (gatsspg_debug_set_trace): 8 x u64 per workgroup
+// [hw_id, xcc_id, t_entry, t_after_prologue?, t_after_mainloop, t_end, rt, ct], 100 MHz wall clock
+unsigned long long* g_trace = nullptr;
+
+template <class T, int ABL = 0>
 __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                    const float* __restrict__ Z, const float* __restrict__ MSG,
-                                                   float* __restrict__ U, float* __restrict__ statpart, ColLayout L) {
+                                                   float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
+                                                   unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned long long t_entry = trace ? wall_clock64() : 0;
     int rt, ct;
     const int NT = L.ld / T::BN;
     constexpr int MT = 512 / T::BM;
@@ -196,15 +200,12 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
     const float* A = W0 + (size_t)rt * T::BM * 512;
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
-    gemm_mainloop<T>(
-        acc, smem, 512 / BK,
-        [&](int kt, int r, int c) { return ldg4(A + (size_t)r * 512 + kt * BK + c); },
-        [&](int kt, int k, int c) {
-            const float* src = kt < 8 ? Z + (size_t)(kt * BK + k) * ld : MSG + (size_t)((kt - 8) * BK + k) * ld;
-            return ldg4(src + c0 + c);
-        });
+    auto al = [&](int kt) { return A + kt * BK; };
+    auto bl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : MSG + (size_t)(kt - 8) * BK * ld) + c0; };
+    gemm_mainloop<T, decltype(al), decltype(bl), ABL>(acc, smem, 512 / BK, al, 512, bl, ld);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    const unsigned long long t_loop = trace ? wall_clock64() : 0;
     const TileSeg ts = tile_seg(L, c0, T::BN);
     constexpr int TS = T::BN + 1;
     float* Tl = smem;  // [BM][65]
@@ -231,6 +232,12 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
         }
         statpart[((size_t)ct * 2 + 0) * 512 + rt * T::BM + tid] = s;
         statpart[((size_t)ct * 2 + 1) * 512 + rt * T::BM + tid] = s2;
+    }
+    if (trace && tid == 0) {
+        unsigned long long* r = trace + (size_t)blockIdx.x * 8;
+        r[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        r[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        r[2] = t_entry; r[3] = 0; r[4] = t_loop; r[5] = wall_clock64(); r[6] = rt; r[7] = ct;
     }
 }
 
@@ -297,14 +304,16 @@ __global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ W3,
     const float* A = W3 + (size_t)rt * T::BM * 512;
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
-    auto al = [&](int kt, int r, int c) { return ldg4(A + (size_t)r * 512 + kt * BK + c); };
-    auto bl = [&](int kt, int k, int c) { return ldg4(U + (size_t)(kt * BK + k) * ld + c0 + c); };
-    auto ba = [&](int kt, int k) { return make_float2(mean[kt * BK + k], rstd[kt * BK + k]); };
+    auto al = [&](int kt) { return A + kt * BK; };
+    auto bl = [&](int kt) { return U + (size_t)kt * BK * ld + c0; };
+    auto xm = [&](int kt) { return mean + kt * BK; };
+    auto xr = [&](int kt) { return rstd + kt * BK; };
     auto bx = [](vf4& v, float2 ms) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fmaxf((v[q] - ms.x) * ms.y, 0.f);
     };
-    gemm_mainloop<T, decltype(al), decltype(bl), decltype(ba), decltype(bx), ABL>(acc, smem, 512 / BK, al, bl, ba, bx);
+    gemm_mainloop_ex<T, decltype(al), decltype(bl), decltype(xm), decltype(xr), decltype(bx), true, ABL>(
+        acc, smem, 512 / BK, al, 512, bl, ld, xm, xr, bx);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -337,9 +346,8 @@ __global__ __launch_bounds__(256) void final_proj_norm_kernel(const float* __res
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     gemm_mainloop<T>(
-        acc, smem, D / BK,
-        [&](int kt, int r, int c) { return ldg4(Wf + (size_t)r * D + kt * BK + c); },
-        [&](int kt, int k, int c) { return ldg4(Z + (size_t)(kt * BK + k) * ld + c0 + c); });
+        acc, smem, D / BK, [&](int kt) { return Wf + kt * BK; }, D,
+        [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     float ss = 0.f;
@@ -390,9 +398,8 @@ __global__ __launch_bounds__(256) void score_exp_kernel(const float* __restrict_
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     gemm_mainloop<T>(
-        acc, smem, D / BK,
-        [&](int kt, int k, int c) { return ldg4(Ap + (size_t)(kt * BK + k) * ld + c); },
-        [&](int kt, int k, int c) { return ldg4(Bp + (size_t)(kt * BK + k) * ld + c); });
+        acc, smem, D / BK, [&](int kt) { return Ap + (size_t)kt * BK * ld; }, ld,
+        [&](int kt) { return Bp + (size_t)kt * BK * ld; }, ld);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
     constexpr int TS = T::BN + 1;
@@ -447,9 +454,8 @@ __global__ __launch_bounds__(256) void gats_wlt_kernel(const float* __restrict__
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     gemm_mainloop<T>(
-        acc, smem, D / BK,
-        [&](int kt, int k, int c) { return ldg4(W + (size_t)(kt * BK + k) * D + rt * 64 + c); },
-        [&](int kt, int k, int c) { return ldg4(P + (size_t)(kt * BK + k) * ld + c0 + c); });
+        acc, smem, D / BK, [&](int kt) { return W + (size_t)kt * BK * D + rt * 64; }, D,
+        [&](int kt) { return P + (size_t)kt * BK * ld + c0; }, ld);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -515,12 +521,13 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-template <class T>
+template <class T, int ABL = 0>
 static void launch_mlp0_t(const float* W0, const float* b0, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    GATSSPG_BIG_LDS_ONCE(mlp0_kernel<T>);
+    auto kern = mlp0_kernel<T, ABL>;
+    GATSSPG_BIG_LDS_ONCE(kern);
     const int NT = w.L.ld / T::BN;
-    GATSSPG_LAUNCH(hk, KID_MLP0, s, mlp0_kernel<T>, dim3(xcd_grid(512 / T::BM, NT)), dim3(256),
-                   shaped_lds(smem_bytes<T>(), 512 / T::BM * NT), s, W0, b0, w.Z, w.MSG, w.U, w.statpart, w.L);
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, kern, dim3(xcd_grid(512 / T::BM, NT)), dim3(256),
+                   shaped_lds(smem_bytes<T>(), 512 / T::BM * NT), s, W0, b0, w.Z, w.MSG, w.U, w.statpart, w.L, g_trace);
 }
 template <class T, int ABL = 0>
 static void launch_mlp3_t(const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk) {
@@ -534,7 +541,9 @@ static void launch_mlp3_t(const float* W3, const float* b3, const Workspace& w, 
 void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const Workspace& w, hipStream_t s,
                 ProfileHook* hk) {
     static const int t0 = env_int("GATSSPG_MLP0_TILE", 0), t3 = env_int("GATSSPG_MLP3_TILE", 0);
-    if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
+    if (t0 == 11) launch_mlp0_t<Mlp0Tile, 1>(W0, b0, w, s, hk);        // ablations (profiling only, wrong results)
+    else if (t0 == 12) launch_mlp0_t<Mlp0Tile, 2>(W0, b0, w, s, hk);
+    else if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
     else launch_mlp0_t<Mlp0Tile>(W0, b0, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
     if (t3 == 11) launch_mlp3_t<Mlp3Tile, 1>(W3, b3, w, s, hk);        // ablation: no global loads in the loop

@@ -1,8 +1,7 @@
 // fp32 MFMA GEMM main loop for gfx950 (v_mfma_f32_32x32x2_f32: exact f32 FMA chain at the
 // 157 TFLOP/s matrix rate).  C[BM x BN] += A[BM x K] * B[K x BN], one 256-thread workgroup
 // (4 wave64s arranged WM x WN), K consumed in BK=32 slabs, LDS double-buffered with register
-// staging: the global loads of slab t+1 are issued before the MFMAs of slab t and written to the
-// other LDS buffer after them -- one barrier per slab (cdna guide T14 "issue early / write late").
+// staging two slabs ahead (two register sets) -- one barrier per slab.
 //
 // Operand layouts
 //   A row-major [M][K] (weights): LDS image [BM][BK+4]; the +4 pad makes the ds_read_b128
@@ -46,25 +45,26 @@ struct GemmTile {
 // row (within a 32x32 MFMA tile) held by accumulator register r of a lane in half `half`
 __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// aload(kt, r, c): float4 of the A slab kt.  row-major A: rows r of the tile, k offset c (0,4,..,28).
-//                  KM A: slab row k = r (0..31), tile column c (multiple of 4).
-// bload(kt, k, c): float4 of B slab kt, slab row k (0..31), tile column c (multiple of 4).
-// baux(kt, k):     per-row float2 fetched together with the B slab (e.g. InstanceNorm mean / rstd);
-// bxform(v, aux):  applied to the B registers when they are written to LDS (after the MFMAs), so
-//                  the raw load has a whole slab of MFMA time to land.
-struct NoAux {
-    __device__ __forceinline__ float2 operator()(int, int) const { return make_float2(0.f, 0.f); }
-};
+// Operand access is described by wave-uniform slab pointers plus loop-invariant per-thread byte
+// offsets, so the steady-state loop carries no per-thread address arithmetic (the loads use the
+// scalar-base + 32-bit-VGPR-offset form):
+//   a_slab(kt): pointer to A slab kt.  row-major A: &A[row0][kt*32] (row stride lda);
+//               KM A: &A_km[kt*32][m0] (row stride lda).
+//   b_slab(kt): pointer to B slab kt: &B[kt*32][col0] (row stride ldb).
+//   x_slab(kt): pointer to 32 per-row float2 (e.g. InstanceNorm mean / rstd) or nullptr-like dummy;
+//   bxform(v, aux): applied to the B registers when they are written to LDS.
 struct NoXform {
     __device__ __forceinline__ void operator()(vf4&, float2) const {}
 };
+__device__ __forceinline__ vf4 ldg4_off(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const vf4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 
 // ABLATE (profiling only, wrong results): 1 = no global loads in the steady-state loop,
-//                                         2 = no global loads and no LDS writes (pure LDS-read + MFMA loop)
-//                                         3 = steady-state loop skipped (fixed cost: prologue + 1 slab + epilogue)
-template <class T, class ALoad, class BLoad, class BAux = NoAux, class BXform = NoXform, int ABLATE = 0>
-__device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ALoad aload,
-                                              BLoad bload, BAux baux = BAux(), BXform bxform = BXform()) {
+//   2 = no global loads and no LDS writes, 3 = steady-state loop cut to one step pair
+template <class T, class ASlab, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, int ABLATE = 0>
+__device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
+                                                 BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform) {
     constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -72,99 +72,154 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float
     const int wm = wave / T::WN, wn = wave % T::WN;
     const int half = lane >> 5, l31 = lane & 31;
 
-    vf4 ra[T::A_VEC], rb[T::B_VEC];
-    float2 rx[T::B_VEC];
+    // loop-invariant per-thread byte offsets (global) and LDS float offsets of the staging slots
+    unsigned a_goff[T::A_VEC], b_goff[T::B_VEC], x_goff[T::B_VEC];
+    int a_soff[T::A_VEC], b_soff[T::B_VEC];
+#pragma unroll
+    for (int p = 0; p < T::A_VEC; ++p) {
+        const int idx = p * 256 + tid;
+        if constexpr (T::AKM) {
+            const int k = idx / (BM / 4), m = (idx % (BM / 4)) * 4;
+            a_goff[p] = 4u * (unsigned)(k * lda + m);
+            a_soff[p] = k * BM + m;
+        } else {
+            const int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
+            a_goff[p] = 4u * (unsigned)(r * lda + c);
+            a_soff[p] = r * T::A_STRIDE + c;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < T::B_VEC; ++p) {
+        const int idx = p * 256 + tid;
+        const int k = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
+        b_goff[p] = 4u * (unsigned)(k * ldb + c);
+        x_goff[p] = 4u * (unsigned)k;
+        b_soff[p] = T::A_FLOATS + k * BN + c;
+    }
+    // fragment read offsets (floats)
+    int afrag[TM], bfrag[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+        afrag[tm] = T::AKM ? (half * 16) * BM + (wm * TM + tm) * 32 + l31 : ((wm * TM + tm) * 32 + l31) * T::A_STRIDE + half * 16;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bfrag[tn] = T::A_FLOATS + (half * 16) * BN + (wn * TN + tn) * 32 + l31;
 
-    auto gload = [&](int kt) {
+    // two staging register sets: slab t+1 and slab t+2 are both in flight while slab t is computed
+    vf4 ra0[T::A_VEC], rb0[T::B_VEC], ra1[T::A_VEC], rb1[T::B_VEC];
+    float2 rx0[T::B_VEC], rx1[T::B_VEC];
+
+    auto gload = [&](int kt, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC], float2(&rx)[T::B_VEC]) {
+        const float* as = a_slab(kt);
+        const float* bs = b_slab(kt);
 #pragma unroll
-        for (int p = 0; p < T::A_VEC; ++p) {
-            const int idx = p * 256 + tid;
-            if constexpr (T::AKM) {
-                ra[p] = aload(kt, idx / (BM / 4), (idx % (BM / 4)) * 4);
-            } else {
-                ra[p] = aload(kt, idx / (BK / 4), (idx % (BK / 4)) * 4);
-            }
-        }
+        for (int p = 0; p < T::A_VEC; ++p) ra[p] = ldg4_off(as, a_goff[p]);
 #pragma unroll
-        for (int p = 0; p < T::B_VEC; ++p) {
-            const int idx = p * 256 + tid;
-            rb[p] = bload(kt, idx / (BN / 4), (idx % (BN / 4)) * 4);
-            rx[p] = baux(kt, idx / (BN / 4));
+        for (int p = 0; p < T::B_VEC; ++p) rb[p] = ldg4_off(bs, b_goff[p]);
+        if constexpr (HAS_AUX) {
+            const float* xm = x_mean(kt);
+            const float* xr = x_rstd(kt);
+#pragma unroll
+            for (int p = 0; p < T::B_VEC; ++p)
+                rx[p] = make_float2(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(xm) + x_goff[p]),
+                                    *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xr) + x_goff[p]));
         }
     };
-    auto swrite = [&](float* stage) {
-        float* As = stage;
-        float* Bs = stage + T::A_FLOATS;
+    auto swrite = [&](float* stage, const vf4(&ra)[T::A_VEC], const vf4(&rb)[T::B_VEC], const float2(&rx)[T::B_VEC]) {
 #pragma unroll
-        for (int p = 0; p < T::A_VEC; ++p) {
-            const int idx = p * 256 + tid;
-            if constexpr (T::AKM) {
-                *reinterpret_cast<vf4*>(As + (idx / (BM / 4)) * BM + (idx % (BM / 4)) * 4) = ra[p];
-            } else {
-                *reinterpret_cast<vf4*>(As + (idx / (BK / 4)) * T::A_STRIDE + (idx % (BK / 4)) * 4) = ra[p];
-            }
-        }
+        for (int p = 0; p < T::A_VEC; ++p) *reinterpret_cast<vf4*>(stage + a_soff[p]) = ra[p];
 #pragma unroll
         for (int p = 0; p < T::B_VEC; ++p) {
-            const int idx = p * 256 + tid;
             vf4 v = rb[p];
-            bxform(v, rx[p]);
-            *reinterpret_cast<vf4*>(Bs + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4) = v;
+            if constexpr (HAS_AUX) bxform(v, rx[p]);
+            *reinterpret_cast<vf4*>(stage + b_soff[p]) = v;
         }
     };
-    auto compute = [&](const float* stage) {
-        const float* As = stage;
-        const float* Bs = stage + T::A_FLOATS;
-        float a[TM][16];
+    // fragments of one half slab (8 k-steps per lane half)
+    auto read_frags = [&](const float* stage, int h, float (&a)[TM][8], float (&b)[TN][8]) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             if constexpr (T::AKM) {
 #pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    a[tm][s] = As[(half * 16 + s) * BM + wm * TM * 32 + tm * 32 + l31];
+                for (int s = 0; s < 8; ++s) a[tm][s] = stage[afrag[tm] + (h * 8 + s) * BM];
             } else {
-                const vf4* ap =
-                    reinterpret_cast<const vf4*>(As + (wm * TM * 32 + tm * 32 + l31) * T::A_STRIDE + half * 16);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const vf4 x = ap[v];
-                    a[tm][4 * v + 0] = x[0]; a[tm][4 * v + 1] = x[1]; a[tm][4 * v + 2] = x[2]; a[tm][4 * v + 3] = x[3];
-                }
+                const vf4* ap = reinterpret_cast<const vf4*>(stage + afrag[tm] + h * 8);
+                const vf4 x = ap[0], y = ap[1];
+                a[tm][0] = x[0]; a[tm][1] = x[1]; a[tm][2] = x[2]; a[tm][3] = x[3];
+                a[tm][4] = y[0]; a[tm][5] = y[1]; a[tm][6] = y[2]; a[tm][7] = y[3];
             }
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            float bv[TN];
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) bv[tn] = Bs[(half * 16 + s) * BN + wn * TN * 32 + tn * 32 + l31];
+            for (int s = 0; s < 8; ++s) b[tn][s] = stage[bfrag[tn] + (h * 8 + s) * BN];
+    };
+    auto mfma4 = [&](const float (&a)[TM][8], const float (&b)[TN][8], int s0) {
+#pragma unroll
+        for (int s = s0; s < s0 + 4; ++s)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], bv[tn], acc[tm][tn], 0, 0, 0);
-        }
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+    };
+    // One step: compute slab from `cur`; in the shadow of the MFMAs (a 32x32x2 MFMA occupies the matrix
+    // pipe for 64 cycles while the wave is free to issue independent memory instructions) start the global
+    // loads of the slab three steps ahead into the register set `set` just freed, fetch the second half of
+    // the fragments, and write the slab one step ahead (registers filled two steps ago) into `nxt`.
+    // sched_barrier(0) between the groups keeps hipcc from regrouping them.
+    auto step = [&](const float* cur, float* nxt, int kt_load, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC],
+                    float2(&rx)[T::B_VEC], vf4(&wa)[T::A_VEC], vf4(&wb)[T::B_VEC], float2(&wx)[T::B_VEC], bool first) {
+        float a0[TM][8], b0[TN][8], a1[TM][8], b1[TN][8];
+        (void)first;
+        read_frags(cur, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(a0, b0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(cur, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(a0, b0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ABLATE <= 1) swrite(nxt, wa, wb, wx);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(a1, b1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ABLATE == 0) gload(kt_load, ra, rb, rx);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(a1, b1, 4);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
-    gload(0);
-    swrite(smem);
+    // Pipeline (prefetch distance 2): during step i the LDS buffer (i+1)&1 is free (everyone passed the
+    // barrier that ended step i-1), so slab i+1 -- loaded two steps ago into register set i&1... see below
+    float* buf0 = smem;
+    float* buf1 = smem + T::STAGE_FLOATS;
+    const int last = KT - 1;
+    gload(0, ra0, rb0, rx0);
+    swrite(buf0, ra0, rb0, rx0);
+    gload(min(1, last), ra0, rb0, rx0);   // set 0 <- slab 1
+    gload(min(2, last), ra1, rb1, rx1);   // set 1 <- slab 2
     __syncthreads();
-    // Steady state: branch-free body (the last slab is peeled) so that hipcc cannot sink the global
-    // loads into a conditional block next to their vmcnt wait; sched_barrier pins the issue order
-    // loads -> MFMAs -> LDS writes, i.e. the loads have the whole slab of MFMA time to land.
-    for (int kt = 0; kt + 1 < (ABLATE == 3 ? 1 : KT); ++kt) {
-        float* cur = smem + (kt & 1) * T::STAGE_FLOATS;
-        float* nxt = smem + ((kt + 1) & 1) * T::STAGE_FLOATS;
-        if constexpr (ABLATE == 0) gload(kt + 1);
-        asm volatile("" ::: "memory");  // SelectionDAG-level pin (sched_barrier alone is not a memory fence)
-        __builtin_amdgcn_sched_barrier(0);
-        compute(cur);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" ::: "memory");
-        if constexpr (ABLATE <= 1) swrite(nxt);
+    // step i (even): compute buf0; write slab i+1 (set 0) -> buf1; then reload set 0 <- slab i+3
+    // step i+1 (odd): compute buf1; write slab i+2 (set 1) -> buf0; then reload set 1 <- slab i+4
+    // The write of a set precedes its reload inside a step (the reload is issued after the writes were
+    // issued; the LDS write reads its registers at issue).  Slab indices are clamped: the last loads and
+    // writes are redundant but harmless; KT is even for every GEMM here (2, 8, 16), the body is branch-free.
+    const int KTL = ABLATE == 3 ? 2 : KT;
+    for (int i = 0; i < KTL; i += 2) {
+        step(buf0, buf1, min(i + 3, last), ra0, rb0, rx0, ra0, rb0, rx0, i == 0);
+        __syncthreads();
+        step(buf1, buf0, min(i + 4, last), ra1, rb1, rx1, ra1, rb1, rx1, false);
         __syncthreads();
     }
-    compute(smem + ((KT - 1) & 1) * T::STAGE_FLOATS);
-    __syncthreads();  // callers re-use the LDS for their epilogue
+}
+
+// convenience wrapper without per-row aux / transform
+template <class T, class ASlab, class BSlab, int ABLATE = 0>
+__device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
+                                              BSlab b_slab, int ldb) {
+    auto nox = [](int) { return static_cast<const float*>(nullptr); };
+    gemm_mainloop_ex<T, ASlab, BSlab, decltype(nox), decltype(nox), NoXform, false, ABLATE>(acc, smem, KT, a_slab, lda, b_slab,
+                                                                                          ldb, nox, nox, NoXform());
 }
 
 template <int TM, int TN>

@@ -1,0 +1,37 @@
+"""Debug: per-workgroup timeline of one mlp0_kernel launch (entry / loop end / exit, CU placement)."""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from onepose_amd import _native
+dev = torch.device("cuda:0")
+w = bench.Weights(dev); r = bench.Runner(dev, w)
+lib = w.engine.lib
+lib.gatsspg_debug_set_trace.argtypes = [ctypes.c_void_p]; lib.gatsspg_debug_set_trace.restype = None
+G = 8 * 4 * 16
+buf = torch.zeros(G * 8, dtype=torch.int64, device=dev)
+for i in range(5): r.step(i)
+torch.cuda.synchronize()
+lib.gatsspg_debug_set_trace(buf.data_ptr())
+r.step(0)
+torch.cuda.synchronize()
+lib.gatsspg_debug_set_trace(None)
+t = buf.cpu().numpy().reshape(G, 8)
+t = t[t[:, 5] != 0]
+print("MLP0_TILE", os.environ.get("GATSSPG_MLP0_TILE"))
+# the buffer holds the LAST mlp0 launch of the frame (every launch overwrites it)
+t0 = t[:, 2].min()
+ent, loop, end = (t[:, 2] - t0) / 100.0, (t[:, 4] - t0) / 100.0, (t[:, 5] - t0) / 100.0
+print(f"blocks {len(t)}  entry: min {ent.min():.2f} med {np.median(ent):.2f} max {ent.max():.2f} us")
+print(f"mainloop(+prologue) duration: min {(loop-ent).min():.2f} med {np.median(loop-ent):.2f} max {(loop-ent).max():.2f} us")
+print(f"epilogue duration: min {(end-loop).min():.2f} med {np.median(end-loop):.2f} max {(end-loop).max():.2f} us")
+print(f"block end: min {end.min():.2f} med {np.median(end):.2f} p90 {np.percentile(end,90):.2f} max {end.max():.2f} us")
+xcc = t[:, 1] & 0xf
+for x in range(8):
+    m = xcc == x
+    print(f" xcc{x}: n={m.sum()} entry {ent[m].min():.2f}-{ent[m].max():.2f}  end {end[m].min():.2f}-{end[m].max():.2f}  med dur {np.median((end-ent)[m]):.2f}")
+cu = (t[:, 1] & 0xf) * 4096 + ((t[:, 0] >> 13) & 7) * 256 + ((t[:, 0] >> 8) & 0xf)
+u, c = np.unique(cu, return_counts=True)
+print("blocks per CU:", dict(zip(*np.unique(c, return_counts=True))))
+one = np.isin(cu, u[c == 1])
+print(f"dur on CUs with 1 block: {np.median((end-ent)[one]):.2f} us; with 2 blocks: {np.median((end-ent)[~one]):.2f} us")
