@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
                                                    unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned long long t_entry = trace ? wall_clock64() : 0;
+    const unsigned long long c_entry = trace ? clock64() : 0;
     int rt, ct;
     const int NT = L.ld / T::BN;
     constexpr int MT = 512 / T::BM;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
         unsigned long long* r = trace + (size_t)blockIdx.x * 8;
         r[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
         r[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        r[2] = t_entry; r[3] = 0; r[4] = t_loop; r[5] = wall_clock64(); r[6] = rt; r[7] = ct;
+        r[2] = t_entry; r[3] = clock64() - c_entry; r[4] = t_loop; r[5] = wall_clock64(); r[6] = rt; r[7] = ct;
     }
 }
 

@@ -2,6 +2,7 @@
 // aggregation, the dual-softmax finalisation with row/column arg-max, the mutual-NN tail, the
 // one-time weight packing and the (off-path) KeypointEncoder.
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/gatsspg.h"
 #include "gatsspg_launch.h"
@@ -169,6 +170,130 @@ __global__ __launch_bounds__(256) void gats_leaf8_kernel(const float* __restrict
     }
 }
 
+// num_leaf == 8, 4 points (32 leaf columns = one 128-byte line per channel row) per workgroup: 8 float4 per
+// thread (~70 VGPRs -> 7 workgroups per CU, 224 KiB of loads in flight per CU) and 2x more workgroups
+// than the 8-point variant (finer tail).  Consecutive tiles are mapped to the same XCD (workgroup id g
+// runs on XCD g % 8) so the 16-byte output pieces of one 128-byte line meet in one L2.
+__global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __restrict__ u1, const float* __restrict__ u2,
+                                                           const float* __restrict__ leaves, const float* Z, float* dst,
+                                                           ColLayout L, int flags, int raw_out, int ntiles) {
+    __shared__ float hs[D * 4];
+    __shared__ float red3[4][4];
+    __shared__ float redl[4][32];
+    __shared__ float coef[4][9];
+    const int f = blockIdx.y;
+    // bijective XCD-contiguous remap (cdna guide T1, non-multiple-of-8 safe)
+    int tile;
+    {
+        const int g = blockIdx.x, xcd = g & 7, q = ntiles >> 3, r = ntiles & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (g >> 3);
+    }
+    const int n0 = tile * 4;
+    const int pv = min(4, L.n2 - n0);
+    const size_t lrow = (size_t)L.n2 * 8;
+    const float* Lf = leaves + (size_t)f * D * lrow + (size_t)n0 * 8;
+    const size_t ycol = (size_t)f * L.np + L.n1p + n0;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane >> 3, c4 = lane & 7;
+    const int pt = c4 >> 1, lh = c4 & 1;
+    const bool valid = pt < pv;
+
+    float4 v[8];
+    float u1r[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int ch = p * 32 + w * 8 + r;
+        v[p] = valid ? *reinterpret_cast<const float4*>(Lf + (size_t)ch * lrow + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        u1r[p] = u1[ch];
+    }
+    {
+        const float4 a = *reinterpret_cast<const float4*>(Z + (size_t)tid * L.ld + ycol);
+        const float hv[4] = {a.x, a.y, a.z, a.w};
+        const float u2v = u2[tid];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hs[tid * 4 + i] = hv[i];
+            float s = hv[i] * u2v;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) red3[w][i] = s;
+        }
+    }
+    {
+        float dl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            dl[0] += v[p].x * u1r[p]; dl[1] += v[p].y * u1r[p]; dl[2] += v[p].z * u1r[p]; dl[3] += v[p].w * u1r[p];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dl[j] += __shfl_xor(dl[j], 8);
+            dl[j] += __shfl_xor(dl[j], 16);
+            dl[j] += __shfl_xor(dl[j], 32);
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) redl[w][c4 * 4 + j] = dl[j];
+        }
+    }
+    __syncthreads();
+    if (tid < 4) {
+        const int include_self = flags & GATSSPG_FLAG_INCLUDE_SELF;
+        const float s3 = (red3[0][tid] + red3[1][tid]) + (red3[2][tid] + red3[3][tid]);
+        float e[9];
+        e[0] = lrelu02(s3 + s3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = tid * 8 + j;
+            e[1 + j] = lrelu02(s3 + ((redl[0][c] + redl[1][c]) + (redl[2][c] + redl[3][c])));
+        }
+        float m = include_self ? e[0] : e[1];
+#pragma unroll
+        for (int j = 1; j < 9; ++j) m = fmaxf(m, e[j]);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if (j > 0 || include_self) {
+                e[j] = expf(e[j] - m);
+                sum += e[j];
+            }
+        }
+        if (include_self) {
+            coef[tid][0] = e[0] / sum + ((flags & GATSSPG_FLAG_ADDITIONAL) && !raw_out ? 1.f : 0.f);
+#pragma unroll
+            for (int j = 1; j < 9; ++j) coef[tid][j] = e[j] / sum;
+        } else {
+            coef[tid][0] = 1.f;
+#pragma unroll
+            for (int j = 1; j < 9; ++j) coef[tid][j] = (e[j] / sum) / 2.f;
+        }
+    }
+    __syncthreads();
+    const float c0 = coef[pt][0];
+    const float cj0 = coef[pt][1 + lh * 4 + 0], cj1 = coef[pt][1 + lh * 4 + 1];
+    const float cj2 = coef[pt][1 + lh * 4 + 2], cj3 = coef[pt][1 + lh * 4 + 3];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int ch = p * 32 + w * 8 + r;
+        float part = ((cj0 * v[p].x + cj1 * v[p].y) + (cj2 * v[p].z + cj3 * v[p].w));
+        part += __shfl_xor(part, 1);
+        float val = c0 * hs[ch * 4 + pt] + part;
+        if (!raw_out) val = elu_f(val);
+        // gather the 4 points of this channel row into the lane with c4 == 0 -> one 16-byte store
+        const float v1 = __shfl(val, (lane & ~7) | 2), v2 = __shfl(val, (lane & ~7) | 4), v3 = __shfl(val, (lane & ~7) | 6);
+        if (c4 == 0) {
+            float* o = dst + (size_t)ch * L.ld + ycol;
+            if (pv == 4) {
+                *reinterpret_cast<float4*>(o) = make_float4(val, v1, v2, v3);
+            } else {
+                o[0] = val;
+                if (pv > 1) o[1] = v1;
+                if (pv > 2) o[2] = v2;
+            }
+        }
+    }
+}
+
 // generic path (any num_leaf <= 64): one thread per channel, 4 points per workgroup.  Off the
 // benchmarked path; leaf reads are strided, but every configuration the reference accepts runs on
 // the GPU (there is no CPU fallback).
@@ -243,7 +368,12 @@ __global__ __launch_bounds__(256) void gats_generic_kernel(const float* __restri
 void launch_gats(const float* u1, const float* u2, const float* leaves, int num_leaf, int flags, float* dst,
                  const Workspace& w, hipStream_t s, ProfileHook* hk) {
     const int raw_out = (flags & GATSSPG_FLAG_WITH_LINEAR_TRANSFORM) ? 1 : 0;
-    if (num_leaf == 8) {
+    static const int variant = [] { const char* v = getenv("GATSSPG_GATS_TILE"); return v ? atoi(v) : 4; }();
+    if (num_leaf == 8 && variant == 4) {
+        const int nt = (w.L.n2 + 3) / 4;
+        GATSSPG_LAUNCH(hk, KID_GATS, s, gats_leaf8x4_kernel, dim3(nt, w.L.b), dim3(256), 0, s, u1, u2, leaves, w.Z, dst, w.L,
+                       flags, raw_out, nt);
+    } else if (num_leaf == 8) {
         GATSSPG_LAUNCH(hk, KID_GATS, s, gats_leaf8_kernel, dim3((w.L.n2 + 7) / 8, w.L.b), dim3(256), 0, s, u1, u2, leaves, w.Z,
                        dst, w.L, flags, raw_out);
     } else {

@@ -60,12 +60,33 @@ __device__ __forceinline__ vf4 ldg4_off(const float* base, unsigned byte_off) {
     return *reinterpret_cast<const vf4*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// N x { 1 MFMA, 1 instruction of class MASK }  (LLVM SchedGroupMask: 0x8 MFMA, 0x2 VALU, 0x20 VMEM read,
+// 0x100 DS read, 0x200 DS write)
+template <int N, int MASK>
+__device__ __forceinline__ void sched_interleave() {
+    if constexpr (N > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(MASK, 1, 0);
+        sched_interleave<N - 1, MASK>();
+    }
+}
+template <int N>
+__device__ __forceinline__ void sched_interleave_vmem() {
+    if constexpr (N > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        sched_interleave_vmem<N - 1>();
+    }
+}
+
 // ABLATE (profiling only, wrong results): 1 = no global loads in the steady-state loop,
 //   2 = no global loads and no LDS writes, 3 = steady-state loop cut to one step pair
 template <class T, class ASlab, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, int ABLATE = 0>
 __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
                                                  BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform) {
     constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN;
+    constexpr bool FINE_INTERLEAVE = false;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -162,31 +183,55 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
                 for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
     };
-    // One step: compute slab from `cur`; in the shadow of the MFMAs (a 32x32x2 MFMA occupies the matrix
-    // pipe for 64 cycles while the wave is free to issue independent memory instructions) start the global
-    // loads of the slab three steps ahead into the register set `set` just freed, fetch the second half of
-    // the fragments, and write the slab one step ahead (registers filled two steps ago) into `nxt`.
-    // sched_barrier(0) between the groups keeps hipcc from regrouping them.
+    // One step: compute slab from `cur`; start the global loads of the slab three steps ahead into the
+    // register set just freed; write the slab one step ahead (registers filled two steps ago) into `nxt`.
     auto step = [&](const float* cur, float* nxt, int kt_load, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC],
-                    float2(&rx)[T::B_VEC], vf4(&wa)[T::A_VEC], vf4(&wb)[T::B_VEC], float2(&wx)[T::B_VEC], bool first) {
+                    float2(&rx)[T::B_VEC]) {
         float a0[TM][8], b0[TN][8], a1[TM][8], b1[TN][8];
-        (void)first;
-        read_frags(cur, 0, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma4(a0, b0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(cur, 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma4(a0, b0, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ABLATE <= 1) swrite(nxt, wa, wb, wx);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma4(a1, b1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ABLATE == 0) gload(kt_load, ra, rb, rx);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma4(a1, b1, 4);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FINE_INTERLEAVE) {
+            // ONE scheduling region; sched_group_barrier asks for at most one memory instruction in the
+            // shadow of each MFMA.  Measured on mlp0 (128x64 tile): a workgroup alone on its CU 23.1 -> 21.1 us,
+            // but two co-resident workgroups 37.0 -> 40.2 us, so this is off by default.
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(cur, 0, a0, b0);
+            read_frags(cur, 1, a1, b1);
+            if constexpr (ABLATE <= 1) swrite(nxt, ra, rb, rx);
+            if constexpr (ABLATE == 0) gload(kt_load, ra, rb, rx);
+            mfma4(a0, b0, 0);
+            mfma4(a0, b0, 4);
+            mfma4(a1, b1, 0);
+            mfma4(a1, b1, 4);
+            constexpr int NMFMA = 16 * TM * TN;
+            constexpr int NRD = (T::AKM ? TM * 8 : TM * 2) + TN * 4;   // fragment-read instructions per half slab
+            constexpr int NWR = ABLATE <= 1 ? T::A_VEC + T::B_VEC : 0;
+            constexpr int NLD = ABLATE == 0 ? T::A_VEC + T::B_VEC : 0;
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+            sched_interleave<NRD < NMFMA ? NRD : NMFMA, 0x100>();
+            sched_interleave<(NRD + NWR <= NMFMA) ? NWR : 0, 0x200>();
+            sched_interleave_vmem<(NRD + NWR + NLD <= NMFMA) ? NLD : 0>();
+            __builtin_amdgcn_sched_group_barrier(0x8, NMFMA, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // Four MFMA groups with the memory work of the step placed between them (a 32x32x2 f32 MFMA
+            // occupies the matrix pipe for 64 cycles while the wave may issue independent instructions);
+            // sched_barrier(0) between the groups keeps hipcc from regrouping them.
+            read_frags(cur, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(a0, b0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(cur, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(a0, b0, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ABLATE <= 1) swrite(nxt, ra, rb, rx);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(a1, b1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ABLATE == 0) gload(kt_load, ra, rb, rx);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(a1, b1, 4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     // Pipeline (prefetch distance 2): during step i the LDS buffer (i+1)&1 is free (everyone passed the
@@ -206,9 +251,9 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     // writes are redundant but harmless; KT is even for every GEMM here (2, 8, 16), the body is branch-free.
     const int KTL = ABLATE == 3 ? 2 : KT;
     for (int i = 0; i < KTL; i += 2) {
-        step(buf0, buf1, min(i + 3, last), ra0, rb0, rx0, ra0, rb0, rx0, i == 0);
+        step(buf0, buf1, min(i + 3, last), ra0, rb0, rx0);
         __syncthreads();
-        step(buf1, buf0, min(i + 4, last), ra1, rb1, rx1, ra1, rb1, rx1, false);
+        step(buf1, buf0, min(i + 4, last), ra1, rb1, rx1);
         __syncthreads();
     }
 }

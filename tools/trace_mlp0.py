@@ -22,6 +22,8 @@ print("MLP0_TILE", os.environ.get("GATSSPG_MLP0_TILE"))
 # the buffer holds the LAST mlp0 launch of the frame (every launch overwrites it)
 t0 = t[:, 2].min()
 ent, loop, end = (t[:, 2] - t0) / 100.0, (t[:, 4] - t0) / 100.0, (t[:, 5] - t0) / 100.0
+ghz = t[:, 3] / ((t[:, 5] - t[:, 2]) * 10.0)
+print(f"shader clock (s_memtime ticks / wall ns): min {ghz.min():.3f} med {np.median(ghz):.3f} max {ghz.max():.3f} GHz")
 print(f"blocks {len(t)}  entry: min {ent.min():.2f} med {np.median(ent):.2f} max {ent.max():.2f} us")
 print(f"mainloop(+prologue) duration: min {(loop-ent).min():.2f} med {np.median(loop-ent):.2f} max {(loop-ent).max():.2f} us")
 print(f"epilogue duration: min {(end-loop).min():.2f} med {np.median(end-loop):.2f} max {(end-loop).max():.2f} us")
