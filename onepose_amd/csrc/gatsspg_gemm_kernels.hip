@@ -87,11 +87,15 @@ __global__ __launch_bounds__(256) void qkv_kv_kernel(const float* __restrict__ W
             const int q = qi * 32 + mfma_row(r, half);
             out[q * DH + di * 32 + l31] = kv[r];
         }
-        if (tid < DH) {
+        {   // ksum[d] = sum_m K[d][m]: 4 lanes per row (16 columns each, fixed order), combined by 2 shuffles
+            const int d = tid >> 2, qtr = tid & 3;
+            const float* kr = Tl + d * TS + qtr * 16;
             float s = 0.f;
-            const float* kr = Tl + tid * TS;
-            for (int m = 0; m < T::BN; ++m) s += kr[m];
-            out[DH * DH + tid] = s;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) s += kr[m];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            if (qtr == 0) out[DH * DH + d] = s;
         }
     }
 }
@@ -223,16 +227,27 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
                 Tl[row * TS + col] = v;
             }
     __syncthreads();
-    if (tid < T::BM) {
+    {   // 256 / BM lanes per row, each a fixed contiguous column range; combined by shuffles (fixed order)
+        constexpr int LPR = 256 / T::BM;           // lanes per row (2 for BM=128, 1 for BM=256)
+        constexpr int CPL = T::BN / LPR;           // columns per lane
+        const int row = tid / LPR, part = tid % LPR;
+        const float* tr = Tl + row * TS + part * CPL;
         float s = 0.f, s2 = 0.f;
-        const float* tr = Tl + tid * TS;
-        for (int m = 0; m < ts.valid; ++m) {
-            const float v = tr[m];
+#pragma unroll 8
+        for (int m = 0; m < CPL; ++m) {
+            const float v = (part * CPL + m < ts.valid) ? tr[m] : 0.f;
             s += v;
             s2 += v * v;
         }
-        statpart[((size_t)ct * 2 + 0) * 512 + rt * T::BM + tid] = s;
-        statpart[((size_t)ct * 2 + 1) * 512 + rt * T::BM + tid] = s2;
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) {
+            s += __shfl_xor(s, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        if (part == 0) {
+            statpart[((size_t)ct * 2 + 0) * 512 + rt * T::BM + row] = s;
+            statpart[((size_t)ct * 2 + 1) * 512 + rt * T::BM + row] = s2;
+        }
     }
     if (trace && tid == 0) {
         unsigned long long* r = trace + (size_t)blockIdx.x * 8;
@@ -282,8 +297,8 @@ __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restric
 }
 
 // =====================================================================================================
-// K6  mlp.3 with the InstanceNorm + ReLU applied on the B-operand load, bias and residual add in the
-//     epilogue:  Z += W3 relu((u - mean) * rstd) + b3      (GATs_SuperGlue.py:126-128, :59,64)
+// K6  mlp.3 with the InstanceNorm + ReLU applied on the B-operand load; the accumulators start from
+//     residual + bias:  Z = (Z + b3) + W3 relu((u - mean) * rstd)      (GATs_SuperGlue.py:126-128, :59,64)
 // =====================================================================================================
 using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;
 using Mlp3TileTall = GemmTile<128, 64, 2, 2, false>;
@@ -304,7 +319,21 @@ __global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ W3,
     const float* rstd = stats + ((size_t)ts.seg * 2 + 1) * 512;
     const float* A = W3 + (size_t)rt * T::BM * 512;
     f32x16 acc[T::TM][T::TN];
-    zero_acc(acc);
+    // start from the residual + bias: the Z tile is fetched before the main loop instead of after it
+    // (its latency hides under the GEMM; the epilogue becomes a pure store)
+    {
+        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+        const int wm_ = wave_ / T::WN, wn_ = wave_ % T::WN, half_ = lane_ >> 5, l31_ = lane_ & 31;
+#pragma unroll
+        for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rt * T::BM + (wm_ * T::TM + tm) * 32 + mfma_row(r, half_);
+                    acc[tm][tn][r] = Z[(size_t)row * ld + c0 + (wn_ * T::TN + tn) * 32 + l31_] + b3[row];
+                }
+    }
     auto al = [&](int kt) { return A + kt * BK; };
     auto bl = [&](int kt) { return U + (size_t)kt * BK * ld + c0; };
     auto xm = [&](int kt) { return mean + kt * BK; };
@@ -324,8 +353,7 @@ __global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ W3,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * T::BM + (wm * T::TM + tm) * 32 + mfma_row(r, half);
-                float* p = Z + (size_t)row * ld + c0 + (wn * T::TN + tn) * 32 + l31;
-                *p = *p + (acc[tm][tn][r] + b3[row]);
+                Z[(size_t)row * ld + c0 + (wn * T::TN + tn) * 32 + l31] = acc[tm][tn][r];
             }
 }
 
@@ -421,18 +449,23 @@ __global__ __launch_bounds__(256) void score_exp_kernel(const float* __restrict_
             Tl[row * TS + col] = e;
         }
     __syncthreads();
-    if (tid < T::BM) {
-        float s = 0.f;
-        const float* tr = Tl + tid * TS;
-#pragma unroll 8
-        for (int m = 0; m < T::BN; ++m) s += tr[m];
-        rowpart[((size_t)frame * nct + ct) * L.n1p + rt * T::BM + tid] = s;
-    } else if (tid < T::BM + T::BN) {
-        const int c = tid - T::BM;
+    {   // row sums: 2 lanes per row (32 columns each); column sums: 4 lanes per column (32 rows each)
+        const int row = tid >> 1, hp = tid & 1;
+        const float* tr = Tl + row * TS + hp * 32;
         float s = 0.f;
 #pragma unroll 8
-        for (int m = 0; m < T::BM; ++m) s += Tl[m * TS + c];
-        colpart[((size_t)frame * nrt + rt) * L.n2p + ct * T::BN + c] = s;
+        for (int m = 0; m < 32; ++m) s += tr[m];
+        s += __shfl_xor(s, 1);
+        if (hp == 0) rowpart[((size_t)frame * nct + ct) * L.n1p + rt * T::BM + row] = s;
+        const int c = tid & 63, qp = tid >> 6;   // one wave per 32-row quarter: conflict-free column walks
+        float t = 0.f;
+#pragma unroll 8
+        for (int m = 0; m < 32; ++m) t += Tl[(qp * 32 + m) * TS + c];
+        __syncthreads();
+        Tl[qp * 64 + c] = t;   // re-use the tile head for the 4 x 64 quarter sums
+        __syncthreads();
+        if (tid < 64)
+            colpart[((size_t)frame * nrt + rt) * L.n2p + ct * T::BN + tid] = (Tl[tid] + Tl[64 + tid]) + (Tl[128 + tid] + Tl[192 + tid]);
     }
 }
 

@@ -16,19 +16,28 @@ __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void load_state_kernel(const float* __restrict__ dq, const float* __restrict__ d3,
                                                          float* __restrict__ Z, ColLayout L) {
+    // one workgroup per (frame, channel) row; float4 stores (np is a multiple of 128), float4 loads when the
+    // source rows are 16-byte aligned (n1, n2 multiples of 4)
     const int ch = blockIdx.x, f = blockIdx.y;
     float* zr = Z + (size_t)ch * L.ld + (size_t)f * L.np;
     const float* q = dq + ((size_t)f * D + ch) * L.n1;
     const float* y = d3 + ((size_t)f * D + ch) * L.n2;
-    for (int i = threadIdx.x; i < L.np; i += 256) {
-        float v = 0.f;
-        if (i < L.n1p) {
-            if (i < L.n1) v = q[i];
+    const bool vec = ((L.n1 | L.n2) & 3) == 0;
+    for (int i = threadIdx.x * 4; i < L.np; i += 1024) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool side = i >= L.n1p;
+        const int j = side ? i - L.n1p : i;
+        const int n = side ? L.n2 : L.n1;
+        const float* src = side ? y : q;
+        if (vec && j + 3 < n) {
+            v = *reinterpret_cast<const float4*>(src + j);
         } else {
-            const int j = i - L.n1p;
-            if (j < L.n2) v = y[j];
+            if (j < n) v.x = src[j];
+            if (j + 1 < n) v.y = src[j + 1];
+            if (j + 2 < n) v.z = src[j + 2];
+            if (j + 3 < n) v.w = src[j + 3];
         }
-        zr[i] = v;
+        *reinterpret_cast<float4*>(zr + i) = v;
     }
 }
 
