@@ -112,6 +112,15 @@ class Runner:
                                                         ev0.cuda_event, ev1.cuda_event), "gatsspg_forward_profiled")
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return int(json.load(f)[kernel]["bytes"])
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(max_seconds=30.0):
     """The oracle (numpy port of the reference algorithm) on this host, headline shape, batch 1."""
     from oracle import gatsspg_oracle as orc
@@ -211,7 +220,7 @@ def main():
                        "end_to_end_f32_mfma_frac": round(f_alg(N1, N2, NUM_LEAF) * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "kernel": args.kernel + "_kernel", "achieved": round(achieved, 2),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": None, "kernel_ms": round(kern_ms, 5), "flops_per_launch": fl,
+                         "traffic": pmc_traffic(args.kernel), "kernel_ms": round(kern_ms, 5), "flops_per_launch": fl,
                          "how": f"hipEvent pair on the compute stream around launch #0 of {args.kernel}_kernel in each of {K} "
                                 f"steps of a one-frame-at-a-time pass (the throughput pass overlaps {S} frames)"},
         }
