@@ -1,6 +1,6 @@
 """Build libgatsspg_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m onepose_amd.build_ext [--force] [--remarks]
+    python -m onepose_amd.build_ext [--force] [--remarks] [--profiling]
 """
 from __future__ import annotations
 
@@ -31,14 +31,18 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, remarks=False, verbose=True):
-    """Compile every HIP source for gfx950 into onepose_amd/lib/libgatsspg_hip.so."""
-    if not force and not is_stale():
+def build(force=False, remarks=False, verbose=True, profiling=False):
+    """Compile every HIP source for gfx950 into onepose_amd/lib/libgatsspg_hip.so.
+    profiling=True adds -DGATSSPG_PROFILING_BUILD (timing-only ablation variants + the mlp0 timeline hook used by
+    tools/trace_mlp0.py); never ship that build."""
+    if not force and not profiling and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH]
     if remarks:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
+    if profiling:
+        cmd.append("-DGATSSPG_PROFILING_BUILD")
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -47,4 +51,4 @@ def build(force=False, remarks=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, remarks="--remarks" in sys.argv)
+    build(force="--force" in sys.argv, remarks="--remarks" in sys.argv, profiling="--profiling" in sys.argv)

@@ -205,8 +205,10 @@ int gatsspg_forward_profiled(const float* packed, const float* desc2d_query, con
     return 0;
 }
 
-/* debug only (not part of the public header): per-workgroup timeline of mlp0_kernel, 8 u64 per workgroup */
+#ifdef GATSSPG_PROFILING_BUILD
+/* profiling builds only (not part of the public header): per-workgroup timeline of mlp0_kernel */
 void gatsspg_debug_set_trace(void* buf) { g_trace = static_cast<unsigned long long*>(buf); }
+#endif
 
 size_t gatsspg_kenc_scratch_bytes(int b, int n) { return (b < 1 || n < 1) ? 0 : kenc_scratch_bytes(b, n); }
 

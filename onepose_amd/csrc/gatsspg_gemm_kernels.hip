@@ -185,9 +185,14 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
 using Mlp0Tile = GemmTile<128, MLP0_BN, 2, 2, false>;
 using Mlp0TileWide = GemmTile<256, MLP0_BN, 4, 1, false>;
 
-// debug-only per-workgroup timeline (gatsspg_debug_set_trace): 8 x u64 per workgroup
-// [hw_id, xcc_id, t_entry, t_after_prologue?, t_after_mainloop, t_end, rt, ct], 100 MHz wall clock
+// per-workgroup timeline of mlp0_kernel (tools/trace_mlp0.py): 8 x u64 per workgroup
+// [hw_id, xcc_id, t_entry, shader cycles, t_after_mainloop, t_end, rt, ct], 100 MHz wall clock.
+// The pointer is a kernel argument (nullptr = off); it can only be set in a -DGATSSPG_PROFILING_BUILD library.
+#ifdef GATSSPG_PROFILING_BUILD
 unsigned long long* g_trace = nullptr;
+#else
+static constexpr unsigned long long* g_trace = nullptr;
+#endif
 
 template <class T, int ABL = 0>
 __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
@@ -574,16 +579,24 @@ static void launch_mlp3_t(const float* W3, const float* b3, const Workspace& w, 
 
 void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const Workspace& w, hipStream_t s,
                 ProfileHook* hk) {
+    // GATSSPG_MLP0_TILE / GATSSPG_MLP3_TILE select alternative (equally correct) tile shapes; the
+    // ablation variants (wrong results, timing only) exist only in a -DGATSSPG_PROFILING_BUILD library.
     static const int t0 = env_int("GATSSPG_MLP0_TILE", 0), t3 = env_int("GATSSPG_MLP3_TILE", 0);
-    if (t0 == 11) launch_mlp0_t<Mlp0Tile, 1>(W0, b0, w, s, hk);        // ablations (profiling only, wrong results)
-    else if (t0 == 12) launch_mlp0_t<Mlp0Tile, 2>(W0, b0, w, s, hk);
-    else if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
+#ifdef GATSSPG_PROFILING_BUILD
+    if (t0 == 11) launch_mlp0_t<Mlp0Tile, 1>(W0, b0, w, s, hk);        // no global loads in the loop
+    else if (t0 == 12) launch_mlp0_t<Mlp0Tile, 2>(W0, b0, w, s, hk);   // no loads, no LDS writes
+    else
+#endif
+    if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
     else launch_mlp0_t<Mlp0Tile>(W0, b0, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
-    if (t3 == 11) launch_mlp3_t<Mlp3Tile, 1>(W3, b3, w, s, hk);        // ablation: no global loads in the loop
-    else if (t3 == 12) launch_mlp3_t<Mlp3Tile, 2>(W3, b3, w, s, hk);   // ablation: no loads, no LDS writes
-    else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3>(W3, b3, w, s, hk);   // ablation: fixed cost only
-    else if (t3 == 1) launch_mlp3_t<Mlp3TileTall>(W3, b3, w, s, hk);
+#ifdef GATSSPG_PROFILING_BUILD
+    if (t3 == 11) launch_mlp3_t<Mlp3Tile, 1>(W3, b3, w, s, hk);
+    else if (t3 == 12) launch_mlp3_t<Mlp3Tile, 2>(W3, b3, w, s, hk);
+    else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3>(W3, b3, w, s, hk);   // steady-state loop cut: fixed cost only
+    else
+#endif
+    if (t3 == 1) launch_mlp3_t<Mlp3TileTall>(W3, b3, w, s, hk);
     else if (t3 == 2) launch_mlp3_t<Mlp3TileWide>(W3, b3, w, s, hk);
     else launch_mlp3_t<Mlp3Tile>(W3, b3, w, s, hk);
 }

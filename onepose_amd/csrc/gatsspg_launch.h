@@ -34,7 +34,9 @@ inline void hook_after(ProfileHook* h, int kid, hipStream_t s) {
     } while (0)
 
 // gatsspg_gemm_kernels.hip
-extern unsigned long long* g_trace;  // debug-only timeline buffer (nullptr = off)
+#ifdef GATSSPG_PROFILING_BUILD
+extern unsigned long long* g_trace;  // per-workgroup timeline buffer of mlp0_kernel (nullptr = off)
+#endif
 void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook* hk = nullptr);
 void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);

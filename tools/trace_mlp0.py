@@ -1,4 +1,5 @@
-"""Debug: per-workgroup timeline of one mlp0_kernel launch (entry / loop end / exit, CU placement)."""
+"""Per-workgroup timeline of one mlp0_kernel launch (entry / loop end / exit, CU placement, shader clock).
+Needs a profiling build:  python -m onepose_amd.build_ext --force --profiling   (rebuild without it afterwards)."""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
