@@ -286,3 +286,112 @@ def test_native_error_reporting():
     lib = _native.load()
     rc = lib.gatsspg_forward(None, None, None, None, 1, 10, 10, 8, 1, 0.07, 0.2, None, None, None, None, None, None, 0, None)
     assert rc != 0 and b"workspace" in lib.gatsspg_last_error()
+
+
+# ----------------------------------------------------------------------------------------------------
+# execution-model properties of the C ABI: stream semantics, graph capture, more shapes
+# ----------------------------------------------------------------------------------------------------
+def test_n3d_not_multiple_of_4_scalar_finalize_path():
+    """n2 % 4 != 0 takes the scalar conf-finalize path and unaligned conf rows."""
+    sd = synthetic.make_state_dict(6)
+    data = synthetic.make_inputs(b=2, n1=130, n2=1027, num_leaf=8, seed=31)
+    hp = dict(HP, match_threshold=0.0)
+    _, conf_ref, inter = orc.forward(sd, data, hp, return_intermediates=True)
+    conf, m0, m1, s0, s1 = make_model(sd, hp).forward_batched(to_dev(data))
+    assert maxdiff(conf.cpu().numpy(), conf_ref) < CONF_ATOL
+    np.testing.assert_array_equal(m0.cpu().numpy(), inter["batched"]["matches0"])
+    np.testing.assert_array_equal(m1.cpu().numpy(), inter["batched"]["matches1"])
+
+
+def test_frames_in_flight_on_separate_streams_match_serial():
+    """Three frames enqueued concurrently on three HIP streams (own workspace/outputs, shared weights)
+    give bit-identical results to running them one after the other -- the bench's throughput mode."""
+    sd = synthetic.make_state_dict(0)
+    model = make_model(sd, dict(HP, match_threshold=0.0))
+    eng, lib = model.engine, model.engine.lib
+    n1, n2, L = 300, 900, 8
+    frames = [to_dev(synthetic.make_inputs(1, n1, n2, L, seed=40 + i)) for i in range(3)]
+    serial = [model.forward_batched(f) for f in frames]
+    torch.cuda.synchronize()
+    packed = eng.packed_weights(dev())
+    nbytes = lib.gatsspg_workspace_bytes(1, n1, n2, L)
+    outs, keep = [], []
+    streams = [torch.cuda.Stream(dev()) for _ in range(3)]
+    torch.cuda.synchronize()
+    for f, st in zip(frames, streams):
+        ws = torch.empty(nbytes, device=dev(), dtype=torch.uint8)
+        conf = torch.empty(1, n1, n2, device=dev())
+        m0 = torch.empty(1, n1, device=dev(), dtype=torch.int64)
+        m1 = torch.empty(1, n2, device=dev(), dtype=torch.int64)
+        s0, s1 = torch.empty(1, n1, device=dev()), torch.empty(1, n2, device=dev())
+        keep.append(ws)
+        outs.append((conf, m0, m1, s0, s1))
+    torch.cuda.synchronize()
+    for (f, st, ws, o) in zip(frames, streams, keep, outs):
+        rc = lib.gatsspg_forward(packed.data_ptr(), f["descriptors2d_query"].data_ptr(), f["descriptors3d_db"].data_ptr(),
+                                 f["descriptors2d_db"].data_ptr(), 1, n1, n2, L, eng.flags(), 0.07, 0.0, o[0].data_ptr(),
+                                 o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(), ws.data_ptr(),
+                                 ws.numel(), st.cuda_stream)
+        assert rc == 0
+    torch.cuda.synchronize()
+    for a, b in zip(serial, outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
+def test_forward_is_hip_graph_capturable():
+    """The C ABI never allocates or synchronises: a whole forward can be captured and replayed."""
+    sd = synthetic.make_state_dict(0)
+    model = make_model(sd, dict(HP, match_threshold=0.0))
+    eng, lib = model.engine, model.engine.lib
+    n1, n2, L = 200, 520, 8
+    d = to_dev(synthetic.make_inputs(1, n1, n2, L, seed=50))
+    ref = model.forward_batched(d)
+    packed = eng.packed_weights(dev())
+    ws = eng.workspace(1, n1, n2, L, dev())
+    conf = torch.zeros(1, n1, n2, device=dev())
+    m0 = torch.zeros(1, n1, device=dev(), dtype=torch.int64)
+    m1 = torch.zeros(1, n2, device=dev(), dtype=torch.int64)
+    s0, s1 = torch.zeros(1, n1, device=dev()), torch.zeros(1, n2, device=dev())
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        st = torch.cuda.current_stream(dev()).cuda_stream
+        rc = lib.gatsspg_forward(packed.data_ptr(), d["descriptors2d_query"].data_ptr(), d["descriptors3d_db"].data_ptr(),
+                                 d["descriptors2d_db"].data_ptr(), 1, n1, n2, L, eng.flags(), 0.07, 0.0, conf.data_ptr(),
+                                 m0.data_ptr(), m1.data_ptr(), s0.data_ptr(), s1.data_ptr(), ws.data_ptr(), ws.numel(), st)
+        assert rc == 0
+    for _ in range(2):
+        conf.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(conf, ref[0]) and torch.equal(m0, ref[1]) and torch.equal(s1, ref[4])
+
+
+def test_stress_shape_properties():
+    """BASELINE config #5 shape (N_3D = 20000 dense cloud), planted matches: size-independent properties."""
+    sd = synthetic.make_passthrough_state_dict(0)
+    data = synthetic.make_inputs(b=1, n1=1000, n2=20000, num_leaf=8, seed=2, planted=True)
+    model = make_model(sd, HP)
+    pred, conf = model(to_dev(data))
+    assert conf.shape == (1, 1000, 20000) and torch.isfinite(conf).all()
+    assert float(conf.sum(dim=2).max()) <= 1.0 + 1e-4 and float(conf.sum(dim=1).max()) <= 1.0 + 1e-4
+    max0, max1 = conf.max(2), conf.max(1)
+    mutual0 = torch.arange(1000, device=conf.device)[None] == max1.indices.gather(1, max0.indices)
+    exp = torch.where(mutual0 & (max0.values > 0.2), max0.indices, torch.full_like(max0.indices, -1))
+    assert torch.equal(pred["matches0"], exp[0])
+    assert int((pred["matches0"][:500] >= 0).sum()) >= 490
+
+
+def test_lightning_style_wrapper_on_gpu(tmp_path):
+    """inference.py:49-58 pattern with the stand-in wrapper: load_from_checkpoint().cuda().eval().freeze()."""
+    from onepose_amd.checkpoint import LitModelGATsSPG
+    sd = synthetic.make_state_dict(0)
+    torch.save({"state_dict": {"matcher." + k: torch.from_numpy(v) for k, v in sd.items()},
+                "hyper_parameters": dict(HP, match_threshold=0.0)}, tmp_path / "GATsSPG.ckpt")
+    model = LitModelGATsSPG.load_from_checkpoint(str(tmp_path / "GATsSPG.ckpt")).cuda().eval().freeze()
+    data = synthetic.make_inputs(1, 48, 80, 8, seed=1)
+    pred, conf = model(to_dev(data))
+    ref_pred, ref_conf = orc.forward(sd, data, dict(HP, match_threshold=0.0))
+    assert maxdiff(conf.cpu().numpy(), ref_conf) < CONF_ATOL
+    np.testing.assert_array_equal(pred["matches0"].cpu().numpy(), ref_pred["matches0"])
