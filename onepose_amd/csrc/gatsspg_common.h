@@ -19,7 +19,7 @@ constexpr int QKV_BN = 64;    // column tile of the QKV+KV-partial kernel (one K
 constexpr int MLP0_BN = 64;   // column tile of the mlp.0 kernel (one InstanceNorm partial per tile)
 constexpr int SC_BM = 128;    // score kernel row tile (over n1)
 constexpr int SC_BN = 64;     // score kernel column tile (over n2)
-constexpr int CF_ROWS = 16;   // conf-finalize strip height
+constexpr int CF_ROWS = 8;    // conf-finalize strip height (all rows of a strip are loaded at once)
 constexpr int CF_COLS = 1024; // conf-finalize chunk width
 
 // Activation state: channel-major [channels][ld] fp32; frame f owns columns [f*np, (f+1)*np):

@@ -194,7 +194,7 @@ unsigned long long* g_trace = nullptr;
 static constexpr unsigned long long* g_trace = nullptr;
 #endif
 
-template <class T, int ABL = 0>
+template <class T, int ABL = 0, bool GLDS = false>
 __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                    const float* __restrict__ Z, const float* __restrict__ MSG,
                                                    float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
@@ -210,9 +210,18 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
     const float* A = W0 + (size_t)rt * T::BM * 512;
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
-    auto al = [&](int kt) { return A + kt * BK; };
-    auto bl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : MSG + (size_t)(kt - 8) * BK * ld) + c0; };
-    gemm_mainloop<T, decltype(al), decltype(bl), ABL>(acc, smem, 512 / BK, al, 512, bl, ld);
+    // ABL == 5 (profiling): every workgroup streams the SAME weight panel and the SAME column tile (cache-hot operands)
+    const float* Ah = ABL == 5 ? W0 : A;
+    const int ch0 = ABL == 5 ? 0 : c0;
+    auto al = [&](int kt) { return Ah + kt * BK; };
+    auto bl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : MSG + (size_t)(kt - 8) * BK * ld) + ch0; };
+    if constexpr (GLDS) {
+        auto nox = [](int) { return static_cast<const float*>(nullptr); };
+        gemm_mainloop_glds<T, decltype(al), decltype(bl), decltype(nox), decltype(nox), false>(acc, smem, 512 / BK, al, 512,
+                                                                                               bl, ld, nox, nox);
+    } else {
+        gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL)>(acc, smem, 512 / BK, al, 512, bl, ld);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
     const unsigned long long t_loop = trace ? wall_clock64() : 0;
@@ -560,9 +569,9 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-template <class T, int ABL = 0>
+template <class T, int ABL = 0, bool GLDS = false>
 static void launch_mlp0_t(const float* W0, const float* b0, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    auto kern = mlp0_kernel<T, ABL>;
+    auto kern = mlp0_kernel<T, ABL, GLDS>;
     GATSSPG_BIG_LDS_ONCE(kern);
     const int NT = w.L.ld / T::BN;
     GATSSPG_LAUNCH(hk, KID_MLP0, s, kern, dim3(xcd_grid(512 / T::BM, NT)), dim3(256),
@@ -585,9 +594,11 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
 #ifdef GATSSPG_PROFILING_BUILD
     if (t0 == 11) launch_mlp0_t<Mlp0Tile, 1>(W0, b0, w, s, hk);        // no global loads in the loop
     else if (t0 == 12) launch_mlp0_t<Mlp0Tile, 2>(W0, b0, w, s, hk);   // no loads, no LDS writes
+    else if (t0 == 15) launch_mlp0_t<Mlp0Tile, 5>(W0, b0, w, s, hk);   // all workgroups stream the same (cache-hot) panels
     else
 #endif
     if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
+    else if (t0 == 2) launch_mlp0_t<Mlp0Tile, 0, true>(W0, b0, w, s, hk);   // LDS-DMA main loop
     else launch_mlp0_t<Mlp0Tile>(W0, b0, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
 #ifdef GATSSPG_PROFILING_BUILD

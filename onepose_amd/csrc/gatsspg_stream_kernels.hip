@@ -430,10 +430,10 @@ __device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int o
 }
 
 // conf = softmax(S, dim=1) * softmax(S, dim=2) = (E / colsum) * (E / rowsum), in place over E;
-// per 16-row strip the column (max, first arg-max row), per 1024-column chunk the row (max, first
+// per 8-row strip the column (max, first arg-max row), per 1024-column chunk the row (max, first
 // arg-max column).  torch.max on CPU breaks ties with the first index; so do we.
 // VEC: n2 % 4 == 0 -> each thread owns 4 consecutive columns (16-byte accesses); otherwise columns
-// tid + 256 k.  Rows are processed 4 at a time so that 4 loads per thread are in flight.
+// tid + 256 k.
 template <bool VEC>
 __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ conf, const float* __restrict__ rs,
                                                             const float* __restrict__ cs, float* __restrict__ rmax_v,
@@ -456,57 +456,56 @@ __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ 
         cmi[k] = 0;
     }
     const int nrows = min(CF_ROWS, L.n1 - i0);
-    for (int r0 = 0; r0 < nrows; r0 += 4) {
-        float e[4][4];
+    // all CF_ROWS rows of the strip are fetched before any is processed: CF_ROWS x 16 B in flight per thread
+    float e[CF_ROWS][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const size_t base = (size_t)(i0 + r0 + u) * L.n2;
-            if (r0 + u < nrows) {
-                if (VEC) {
-                    if (jc[0] < L.n2) {
-                        const float4 x = *reinterpret_cast<const float4*>(cf + base + jc[0]);
-                        e[u][0] = x.x; e[u][1] = x.y; e[u][2] = x.z; e[u][3] = x.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (jc[k] < L.n2) e[u][k] = cf[base + jc[k]];
+    for (int u = 0; u < CF_ROWS; ++u) {
+        const size_t base = (size_t)(i0 + u) * L.n2;
+        if (u < nrows) {
+            if (VEC) {
+                if (jc[0] < L.n2) {
+                    const float4 x = *reinterpret_cast<const float4*>(cf + base + jc[0]);
+                    e[u][0] = x.x; e[u][1] = x.y; e[u][2] = x.z; e[u][3] = x.w;
                 }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (jc[k] < L.n2) e[u][k] = cf[base + jc[k]];
             }
         }
+    }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = r0 + u;
-            if (r < nrows) {  // uniform over the block
-                const int i = i0 + r;
-                const size_t base = (size_t)i * L.n2;
-                const float rsi = rs[(size_t)f * L.n1p + i];
-                float rv = -INFINITY;
-                int ri = 0x7fffffff;
-                float c[4];
+    for (int u = 0; u < CF_ROWS; ++u) {
+        const int r = u;
+        if (r < nrows) {  // uniform over the block
+            const int i = i0 + r;
+            const size_t base = (size_t)i * L.n2;
+            const float rsi = rs[(size_t)f * L.n1p + i];
+            float rv = -INFINITY;
+            int ri = 0x7fffffff;
+            float c[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (jc[k] < L.n2) {
-                        c[k] = (e[u][k] / csj[k]) * (e[u][k] / rsi);
-                        if (c[k] > cmv[k]) { cmv[k] = c[k]; cmi[k] = i; }
-                        if (c[k] > rv) { rv = c[k]; ri = jc[k]; }
-                    }
+            for (int k = 0; k < 4; ++k) {
+                if (jc[k] < L.n2) {
+                    c[k] = (e[u][k] / csj[k]) * (e[u][k] / rsi);
+                    if (c[k] > cmv[k]) { cmv[k] = c[k]; cmi[k] = i; }
+                    if (c[k] > rv) { rv = c[k]; ri = jc[k]; }
                 }
-                if (VEC) {
-                    if (jc[0] < L.n2) *reinterpret_cast<float4*>(cf + base + jc[0]) = make_float4(c[0], c[1], c[2], c[3]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (jc[k] < L.n2) cf[base + jc[k]] = c[k];
-                }
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    const float ov = __shfl_xor(rv, o);
-                    const int oi = __shfl_xor(ri, o);
-                    argmax_combine(rv, ri, ov, oi);
-                }
-                if (lane == 0) { wv[r][wave] = rv; wi[r][wave] = ri; }
             }
+            if (VEC) {
+                if (jc[0] < L.n2) *reinterpret_cast<float4*>(cf + base + jc[0]) = make_float4(c[0], c[1], c[2], c[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (jc[k] < L.n2) cf[base + jc[k]] = c[k];
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const float ov = __shfl_xor(rv, o);
+                const int oi = __shfl_xor(ri, o);
+                argmax_combine(rv, ri, ov, oi);
+            }
+            if (lane == 0) { wv[r][wave] = rv; wi[r][wave] = ri; }
         }
     }
     __syncthreads();

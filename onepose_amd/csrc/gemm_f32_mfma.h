@@ -258,6 +258,140 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     }
 }
 
+// -------------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the main loop (global_load_lds_dwordx4: memory -> LDS without staging VGPRs or
+// ds_write instructions).  The DMA writes LDS lane-linearly (wave-uniform base + lane * 16 B), so
+//   * the B slab [32][BN] (already row-contiguous) is copied as is: one wave instruction = 1 KiB = 1024/(4 BN) rows;
+//   * the weight slab is stored UNPADDED as [BM][32] and the bank-conflict fix moves to the SOURCE address:
+//     physical 16-byte chunk p of row r holds logical chunk p ^ ((r >> 1) & 7); fragment reads apply the same
+//     XOR (cdna guide rule 21: linear destination + swizzled source + swizzled read).  With it the 16 rows of
+//     every ds_read_b128 lane group hit 16 distinct 16-byte slots.
+// Two LDS buffers, one slab of lookahead: the DMA of slab t+1 is issued at the top of step t (its buffer was
+// released by the barrier that ended step t-1) and drained by vmcnt(0) right before the barrier that ends
+// step t -- a full slab of MFMA time later.  Only for row-major A and GemmTiles whose A/B slabs are whole
+// numbers of 1 KiB pieces per wave.  Optional per-k (mean, rstd) transform of B is applied at fragment-read time.
+// -------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+template <class T, class ASlab, class BSlab, class XSlabA, class XSlabB, bool HAS_AUX>
+__device__ __forceinline__ void gemm_mainloop_glds(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
+                                                   BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd) {
+    static_assert(!T::AKM, "LDS-DMA main loop: row-major A only");
+    constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN;
+    constexpr int A_FL = BM * BK;             // unpadded
+    constexpr int B_FL = BK * BN;
+    constexpr int X_FL = HAS_AUX ? 64 : 0;    // [mean(32) | rstd(32)] per slab
+    constexpr int STAGE = A_FL + B_FL + X_FL;
+    static_assert(2 * STAGE <= T::SMEM_FLOATS, "LDS-DMA image must fit the tile's LDS allocation");
+    constexpr int A_PIECES = A_FL / 256 / 4;  // 1 KiB pieces per wave
+    constexpr int B_PIECES = B_FL / 256 / 4;
+    static_assert(A_PIECES * 4 * 256 == A_FL && B_PIECES * 4 * 256 == B_FL, "slabs must split into 1 KiB pieces per wave");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+
+    // per-lane source byte offsets (loop invariant) and wave-uniform LDS piece offsets
+    unsigned a_goff[A_PIECES], b_goff[B_PIECES];
+#pragma unroll
+    for (int p = 0; p < A_PIECES; ++p) {
+        const int piece = wave * A_PIECES + p;          // 8 rows per piece
+        const int r = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);  // logical chunk stored at physical chunk lane & 7
+        a_goff[p] = 4u * (unsigned)(r * lda + chunk * 4);
+    }
+#pragma unroll
+    for (int p = 0; p < B_PIECES; ++p) {
+        const int piece = wave * B_PIECES + p;          // 256 / BN rows per piece
+        const int fl = piece * 256 + lane * 4;          // float index inside the B slab image
+        b_goff[p] = 4u * (unsigned)((fl / BN) * ldb + (fl % BN));
+    }
+    auto dma = [&](int kt, float* stage) {
+        const char* as = reinterpret_cast<const char*>(a_slab(kt));
+        const char* bs = reinterpret_cast<const char*>(b_slab(kt));
+#pragma unroll
+        for (int p = 0; p < A_PIECES; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(as + a_goff[p]),
+                                             (lds_void*)(stage + (wave * A_PIECES + p) * 256), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < B_PIECES; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(bs + b_goff[p]),
+                                             (lds_void*)(stage + A_FL + (wave * B_PIECES + p) * 256), 16, 0, 0);
+        if constexpr (HAS_AUX) {
+            if (wave == 0) {  // 64 lanes x 4 B = mean[32] | rstd[32]
+                const float* src = lane < 32 ? x_mean(kt) + lane : x_rstd(kt) + (lane - 32);
+                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(stage + A_FL + B_FL), 4, 0, 0);
+            }
+        }
+    };
+    // fragment read offsets (floats)
+    int arow[TM], bfrag[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) arow[tm] = (wm * TM + tm) * 32 + l31;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) bfrag[tn] = A_FL + (half * 16) * BN + (wn * TN + tn) * 32 + l31;
+
+    auto read_frags = [&](const float* stage, int h, float (&a)[TM][8], float (&b)[TN][8]) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int r = arow[tm];
+            const int sw = (r >> 1) & 7;
+            const int c0 = half * 4 + h * 2;   // logical chunks c0, c0 + 1
+            const vf4 x = *reinterpret_cast<const vf4*>(stage + r * BK + ((c0 ^ sw) << 2));
+            const vf4 y = *reinterpret_cast<const vf4*>(stage + r * BK + (((c0 + 1) ^ sw) << 2));
+            a[tm][0] = x[0]; a[tm][1] = x[1]; a[tm][2] = x[2]; a[tm][3] = x[3];
+            a[tm][4] = y[0]; a[tm][5] = y[1]; a[tm][6] = y[2]; a[tm][7] = y[3];
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) b[tn][s] = stage[bfrag[tn] + (h * 8 + s) * BN];
+        if constexpr (HAS_AUX) {
+            const float* xs = stage + A_FL + B_FL + half * 16 + h * 8;   // broadcast reads (uniform per lane half)
+            const vf4 m0 = *reinterpret_cast<const vf4*>(xs), m1 = *reinterpret_cast<const vf4*>(xs + 4);
+            const vf4 r0 = *reinterpret_cast<const vf4*>(xs + 32), r1 = *reinterpret_cast<const vf4*>(xs + 36);
+            const float mm[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+            const float rr[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) b[tn][s] = fmaxf((b[tn][s] - mm[s]) * rr[s], 0.f);
+        }
+    };
+    auto mfma4 = [&](const float (&a)[TM][8], const float (&b)[TN][8], int s0) {
+#pragma unroll
+        for (int s = s0; s < s0 + 4; ++s)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+    };
+
+    float* buf0 = smem;
+    float* buf1 = smem + STAGE;
+    dma(0, buf0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        float* cur = (kt & 1) ? buf1 : buf0;
+        float* nxt = (kt & 1) ? buf0 : buf1;
+        float a0[TM][8], b0[TN][8], a1[TM][8], b1[TN][8];
+        read_frags(cur, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(a0, b0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < KT) dma(kt + 1, nxt);   // wave-uniform branch; DMA has no register results to sink
+        read_frags(cur, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(a0, b0, 4);
+        mfma4(a1, b1, 0);
+        mfma4(a1, b1, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
 // convenience wrapper without per-row aux / transform
 template <class T, class ASlab, class BSlab, int ABLATE = 0>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
