@@ -21,7 +21,10 @@ def dist_env():
 
 def init_process_group(backend=None):
     rank, local_rank, world = dist_env()
-    if world > 1 and not dist.is_initialized():
+    # under torchrun (RANK/WORLD_SIZE exported) the group is initialised even for world == 1, so the
+    # single-GPU box exercises the same RCCL path the 8-GPU run uses
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if (world > 1 or launched) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

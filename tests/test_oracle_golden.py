@@ -90,3 +90,17 @@ def test_oracle_empty_input(golden_meta):
         assert list(out[k].shape) == meta[k][0]
         assert str(out[k].dtype) == meta[k][1].replace("torch.", "")
     assert (out["matches1"] == -1).all()
+
+
+@pytest.mark.parametrize("name", ["rand_small", "planted_small", "ragged_leaf3", "flags_noself_wlt", "flags_wlt_add"])
+def test_torch_oracle_matches_reference(name, golden_meta):
+    """The torch restatement (used as the stock-PyTorch-on-GPU baseline) against the reference goldens."""
+    import torch
+    from oracle import torch_oracle
+    g = load_golden(name)
+    sd, data, hp = case_inputs(golden_meta["cases"][name])
+    pred, conf = torch_oracle.forward({k: torch.from_numpy(v) for k, v in sd.items()},
+                                      {k: torch.from_numpy(v) for k, v in data.items()}, hp)
+    np.testing.assert_allclose(conf.numpy(), g["conf"], atol=ATOL_CONF, rtol=RTOL)
+    np.testing.assert_array_equal(pred["matches0"].numpy(), g["matches0"])
+    np.testing.assert_array_equal(pred["matches1"].numpy(), g["matches1"])
