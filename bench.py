@@ -198,7 +198,17 @@ def main():
             runner.step_profiled(i, args.kernel, events[i][0], events[i][1])
         torch.cuda.synchronize(device)
         latency = (time.perf_counter() - t1) / K
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+        # calibration: the same event pair with nothing between them (the two record packets' own latency is part of
+        # every bracket and is not kernel time -- rocprofv3's dispatch durations do not contain it)
+        cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+        for i, (c0, c1) in enumerate(cal):
+            runner.step(i)                      # same preceding context: a busy stream
+            c0.record(runner.stream)
+            c1.record(runner.stream)
+        torch.cuda.synchronize(device)
+    kern_raw_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+    pair_ms = float(np.median([c0.elapsed_time(c1) for c0, c1 in cal]))
+    kern_ms = kern_raw_ms  # conservative: the bracket contains part of the event packets' own latency (pair_ms is its upper bound)
 
     per_rank = sharding.gather_metrics([K * runner.b, elapsed], device=device)  # the one (RCCL) collective
     value, seconds = sharding.aggregate_throughput(per_rank.cpu())
@@ -220,9 +230,13 @@ def main():
                        "end_to_end_f32_mfma_frac": round(f_alg(N1, N2, NUM_LEAF) * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "kernel": args.kernel + "_kernel", "achieved": round(achieved, 2),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": pmc_traffic(args.kernel), "kernel_ms": round(kern_ms, 5), "flops_per_launch": fl,
+                         "traffic": pmc_traffic(args.kernel), "kernel_ms": round(kern_ms, 5),
+                         "empty_event_pair_ms": round(pair_ms, 5),
+                         "flops_per_launch": fl,
                          "how": f"hipEvent pair on the compute stream around launch #0 of {args.kernel}_kernel in each of {K} "
-                                f"steps of a one-frame-at-a-time pass (the throughput pass overlaps {S} frames)"},
+                                f"steps of a one-frame-at-a-time pass (the throughput pass overlaps {S} frames); the bracket includes "
+                                f"event-packet latency (an empty pair on the same stream reads empty_event_pair_ms), so rocprofv3's "
+                                f"dispatch duration in profiles/ is a few us shorter"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
