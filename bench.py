@@ -107,6 +107,23 @@ class Runner:
     def step(self, i):
         _native.check(self.lib.gatsspg_forward(*self._common(i)), "gatsspg_forward")
 
+    # ---- amortised mode (database cache): reported separately, never as `value` ----
+    def prepare_database(self):
+        nbytes = self.lib.gatsspg_db_cache_bytes(self.b, self.n2)
+        self.db_cache = torch.empty(nbytes // 4, device=self.device)
+        _native.check(self.lib.gatsspg_prepare_database(self.packed.data_ptr(), self.d3.data_ptr(), self.d2db.data_ptr(), self.b,
+                                                        self.n2, NUM_LEAF, self.flags, self.db_cache.data_ptr(), nbytes,
+                                                        self.ws.data_ptr(), self.ws.numel(), self.stream.cuda_stream),
+                      "gatsspg_prepare_database")
+
+    def step_cached(self, i):
+        q = self.queries[i % len(self.queries)]
+        _native.check(self.lib.gatsspg_forward_cached(
+            self.packed.data_ptr(), q.data_ptr(), self.d2db.data_ptr(), self.db_cache.data_ptr(), self.db_cache.numel() * 4,
+            self.b, self.n1, self.n2, NUM_LEAF, self.flags, HP["scale_factor"], HP["match_threshold"], self.conf.data_ptr(),
+            self.m0.data_ptr(), self.m1.data_ptr(), self.s0.data_ptr(), self.s1.data_ptr(), self.ws.data_ptr(),
+            self.ws.numel(), self.stream.cuda_stream), "gatsspg_forward_cached")
+
     def step_profiled(self, i, kernel, ev0, ev1, occurrence=0):
         _native.check(self.lib.gatsspg_forward_profiled(*self._common(i), _native.KERNEL_IDS[kernel], occurrence,
                                                         ev0.cuda_event, ev1.cuda_event), "gatsspg_forward_profiled")
@@ -150,6 +167,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=3, help="query frames kept in flight per GPU (one HIP stream each)")
+    ap.add_argument("--amortised", action="store_true",
+                    help="also report the database-cache mode (query-independent part of the first 3 GNN layers "
+                         "precomputed once per object); informative, never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default=DOMINANT, choices=list(_native.KERNEL_IDS))
     args = ap.parse_args()
@@ -210,6 +230,27 @@ def main():
     pair_ms = float(np.median([c0.elapsed_time(c1) for c0, c1 in cal]))
     kern_ms = kern_raw_ms  # conservative: the bracket contains part of the event packets' own latency (pair_ms is its upper bound)
 
+    amortised = None
+    if args.amortised:
+        for sl in slots:
+            with torch.cuda.stream(sl.stream):
+                sl.prepare_database()
+        torch.cuda.synchronize(device)
+        for i in range(W):
+            slots[i % S].step_cached(i)
+        torch.cuda.synchronize(device)
+        ta = time.perf_counter()
+        for i in range(K):
+            slots[i % S].step_cached(i)
+        torch.cuda.synchronize(device)
+        thr = K / (time.perf_counter() - ta)
+        ta = time.perf_counter()
+        for i in range(K):
+            runner.step_cached(i)
+        torch.cuda.synchronize(device)
+        amortised = {"frames_per_sec": round(thr, 2), "single_frame_latency_ms": round((time.perf_counter() - ta) / K * 1e3, 4),
+                     "note": "3D database resident, its query-independent GNN work cached once per object; bit-identical outputs"}
+
     per_rank = sharding.gather_metrics([K * runner.b, elapsed], device=device)  # the one (RCCL) collective
     value, seconds = sharding.aggregate_throughput(per_rank.cpu())
 
@@ -238,6 +279,8 @@ def main():
                                 f"event-packet latency (an empty pair on the same stream reads empty_event_pair_ms), so rocprofv3's "
                                 f"dispatch duration in profiles/ is a few us shorter"},
         }
+        if amortised:
+            out["amortised_database_mode"] = amortised
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -100,6 +100,22 @@ int gatsspg_forward_profiled(const float* packed, const float* desc2d_query, con
                              int64_t* matches1, float* mscores0, float* mscores1, void* ws, size_t ws_bytes,
                              void* stream, int kernel_id, int occurrence, void* ev_start, void* ev_stop);
 
+/* ---- amortised mode: per-object database cache ------------------------------------
+ * The 3D database (desc3d_db + its leaves desc2d_db) is constant per object (inference.py:113-130) while the
+ * reference recomputes -- and re-uploads, inference.py:86-90 -- everything per frame.  gnn.layers.0 (GATs),
+ * the 3D side of gnn.layers.1 (self) and the 3D-side projections / KV sums of gnn.layers.2 (cross) do not depend
+ * on the query frame; gatsspg_prepare_database computes them once, gatsspg_forward_cached skips them.  Results are
+ * bit-identical to gatsspg_forward (same kernels, same fixed-order reductions).  The cache does not depend on n1.
+ * ws for prepare: at least gatsspg_workspace_bytes(b, 2, n2, num_leaf). */
+size_t gatsspg_db_cache_bytes(int b, int n2);
+int gatsspg_prepare_database(const float* packed, const float* desc3d_db, const float* desc2d_db, int b, int n2,
+                             int num_leaf, int flags, void* cache, size_t cache_bytes, void* ws, size_t ws_bytes,
+                             void* stream);
+int gatsspg_forward_cached(const float* packed, const float* desc2d_query, const float* desc2d_db, const void* cache,
+                           size_t cache_bytes, int b, int n1, int n2, int num_leaf, int flags, float scale_factor,
+                           float match_threshold, float* conf, int64_t* matches0, int64_t* matches1,
+                           float* mscores0, float* mscores1, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- per-stage entry points (the stages gatsspg_forward is made of; used by the parity
  *      tests to check each kernel against the oracle).  They operate on the workspace state. */
 

@@ -48,6 +48,12 @@ SYMBOLS = {
     "gatsspg_forward_profiled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                          c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_size_t, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "gatsspg_db_cache_bytes": (c_size_t, [c_int, c_int]),
+    "gatsspg_prepare_database": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                                         c_void_p, c_size_t, c_void_p]),
+    "gatsspg_forward_cached": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int,
+                                       c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]),
     "gatsspg_load_state": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "gatsspg_store_state": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "gatsspg_gats_layer": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,

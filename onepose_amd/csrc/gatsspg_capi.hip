@@ -71,6 +71,28 @@ void enqueue_attn(const float* packed, int layer, int kind, const Workspace& w, 
     launch_mlp(a + AttnW::W0, a + AttnW::B0, a + AttnW::W3, a + AttnW::B3, w, s, hk);
 }
 
+// ---- database cache: everything of the first three GNN layers that depends only on the
+//      per-object 3D database.  Layout (floats): Y2 [b][256][n2] | QY [b][256][n2] | kvY [b][4][KVP]
+struct DbCache {
+    float *Y2, *QY, *kvY;
+    size_t bytes;
+};
+DbCache carve_cache(void* base, int b, int n2) {
+    DbCache c;
+    float* p = static_cast<float*>(base);
+    const size_t plane = (size_t)b * D * n2;
+    c.Y2 = p;
+    c.QY = p ? p + plane : nullptr;
+    c.kvY = p ? p + 2 * plane : nullptr;
+    c.bytes = sizeof(float) * (2 * plane + (size_t)b * H * KVP);
+    return c;
+}
+Workspace windowed(const Workspace& w, int side) {
+    Workspace v = w;
+    v.L = side_window(w.L, side);
+    return v;
+}
+
 int forward_impl(const float* packed, const float* desc2d_query, const float* desc3d_db, const float* desc2d_db, int b,
                  int n1, int n2, int num_leaf, int flags, float scale_factor, float match_threshold, float* conf,
                  int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, void* ws, size_t ws_bytes,
@@ -209,6 +231,68 @@ int gatsspg_forward_profiled(const float* packed, const float* desc2d_query, con
 /* profiling builds only (not part of the public header): per-workgroup timeline of mlp0_kernel */
 void gatsspg_debug_set_trace(void* buf) { g_trace = static_cast<unsigned long long*>(buf); }
 #endif
+
+size_t gatsspg_db_cache_bytes(int b, int n2) {
+    if (b < 1 || n2 < 2) return 0;
+    return carve_cache(nullptr, b, n2).bytes;
+}
+
+int gatsspg_prepare_database(const float* packed, const float* desc3d_db, const float* desc2d_db, int b, int n2,
+                             int num_leaf, int flags, void* cache, size_t cache_bytes, void* ws, size_t ws_bytes,
+                             void* stream) {
+    Workspace w;
+    if (int e = check_ws(ws, ws_bytes, b, 2, n2, num_leaf, w)) return e;   // 2 dummy (zero) query columns
+    if (!packed || !desc3d_db || !desc2d_db || !cache) return fail("null argument");
+    const DbCache c = carve_cache(cache, b, n2);
+    if (cache_bytes < c.bytes) return fail("database cache too small: %zu < %zu bytes", cache_bytes, c.bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Workspace wy = windowed(w, 1);
+    launch_load_state(nullptr, desc3d_db, w, s);
+    enqueue_gats(packed, 0, desc2d_db, num_leaf, flags, w, s);              // gnn.layers.0 (3D side only by nature)
+    enqueue_attn(packed, 0, GATSSPG_LAYER_SELF, wy, s);                     // gnn.layers.1, 3D side
+    const float* a1 = attn_w(packed, 1);
+    launch_qkv_kv(a1 + AttnW::WQKV, a1 + AttnW::BQKV, wy, s);               // gnn.layers.2: 3D-side Q, KV, ksum
+    launch_store_state(w.Z, nullptr, c.Y2, w, s);
+    launch_store_state(w.Q, nullptr, c.QY, w, s);
+    if (hipMemcpy2DAsync(c.kvY, sizeof(float) * H * KVP, w.kvfin + (size_t)H * KVP, sizeof(float) * 2 * H * KVP,
+                         sizeof(float) * H * KVP, b, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return fail("prepare_database: copy of the KV sums failed");
+    return check_launch("prepare_database");
+}
+
+int gatsspg_forward_cached(const float* packed, const float* desc2d_query, const float* desc2d_db, const void* cache,
+                           size_t cache_bytes, int b, int n1, int n2, int num_leaf, int flags, float scale_factor,
+                           float match_threshold, float* conf, int64_t* matches0, int64_t* matches1, float* mscores0,
+                           float* mscores1, void* ws, size_t ws_bytes, void* stream) {
+    Workspace w;
+    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
+    if (!packed || !desc2d_query || !desc2d_db || !cache) return fail("null input pointer");
+    if (!conf || !matches0 || !matches1 || !mscores0 || !mscores1) return fail("null output pointer");
+    if (!(scale_factor > 0.f)) return fail("scale_factor must be positive");
+    const DbCache c = carve_cache(const_cast<void*>(cache), b, n2);
+    if (cache_bytes < c.bytes) return fail("database cache too small: %zu < %zu bytes", cache_bytes, c.bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Workspace wx = windowed(w, 0);
+    launch_load_state(desc2d_query, c.Y2, w, s);                            // state = [X0 | cached Y2]
+    enqueue_attn(packed, 0, GATSSPG_LAYER_SELF, wx, s);                     // gnn.layers.1, query side only
+    const float* a1 = attn_w(packed, 1);
+    launch_qkv_kv(a1 + AttnW::WQKV, a1 + AttnW::BQKV, wx, s);               // gnn.layers.2: query-side Q, KV, ksum
+    launch_load_columns(nullptr, c.QY, w.Q, w, s);                          // 3D-side Q and KV sums from the cache
+    if (hipMemcpy2DAsync(w.kvfin + (size_t)H * KVP, sizeof(float) * 2 * H * KVP, c.kvY, sizeof(float) * H * KVP,
+                         sizeof(float) * H * KVP, b, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return fail("forward_cached: copy of the KV sums failed");
+    launch_attn_apply(w, 1, s);
+    launch_mlp(a1 + AttnW::W0, a1 + AttnW::B0, a1 + AttnW::W3, a1 + AttnW::B3, w, s);
+    for (int t = 1; t < 4; ++t) {
+        enqueue_gats(packed, t, desc2d_db, num_leaf, flags, w, s);
+        enqueue_attn(packed, 2 * t, GATSSPG_LAYER_SELF, w, s);
+        enqueue_attn(packed, 2 * t + 1, GATSSPG_LAYER_CROSS, w, s);
+    }
+    launch_final_proj_norm(packed + PW_FINAL_W, packed + PW_FINAL_B, w, s);
+    launch_score_exp(w, conf, scale_factor, s);
+    launch_dual_softmax_match(w, conf, match_threshold, matches0, matches1, mscores0, mscores1, s);
+    return check_launch("forward_cached");
+}
 
 size_t gatsspg_kenc_scratch_bytes(int b, int n) { return (b < 1 || n < 1) ? 0 : kenc_scratch_bytes(b, n); }
 

@@ -27,6 +27,10 @@ constexpr int CF_COLS = 1024; // conf-finalize chunk width
 // [n1p, n1p + n2) (padded to n2p).  A "segment" is one (frame, side) pair: seg = 2*f + side.
 struct ColLayout {
     int b, n1, n2, n1p, n2p, np, ld;
+    // active column window of a launch, per frame, in 64-column tiles: tiles [tw_first, tw_first + tw_count) of
+    // every frame (default: the whole frame).  Lets the per-point kernels run on the query side or the 3D side only.
+    int tw_first, tw_count;
+    int side_mask;   // bit 0: 2D-side segments active, bit 1: 3D-side segments (segment-level reduction kernels)
 };
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -36,7 +40,21 @@ __host__ __device__ inline ColLayout make_layout(int b, int n1, int n2) {
     L.b = b; L.n1 = n1; L.n2 = n2;
     L.n1p = round_up(n1, CP); L.n2p = round_up(n2, CP);
     L.np = L.n1p + L.n2p; L.ld = b * L.np;
+    L.tw_first = 0; L.tw_count = L.np / 64; L.side_mask = 3;
     return L;
+}
+
+// layout restricted to one side: side 0 = query (2D) columns, 1 = 3D columns
+__host__ __device__ inline ColLayout side_window(ColLayout L, int side) {
+    L.tw_first = side ? L.n1p / 64 : 0;
+    L.tw_count = (side ? L.n2p : L.n1p) / 64;
+    L.side_mask = side ? 2 : 1;
+    return L;
+}
+// number of active 64-column tiles of a launch, and the global tile index of active tile t
+__host__ __device__ inline int active_tiles(const ColLayout& L) { return L.b * L.tw_count; }
+__host__ __device__ inline int global_tile(const ColLayout& L, int t) {
+    return (t / L.tw_count) * (L.np / 64) + L.tw_first + t % L.tw_count;
 }
 
 struct TileSeg {

@@ -24,8 +24,8 @@ __global__ __launch_bounds__(256) void qkv_kv_kernel(const float* __restrict__ W
     using T = QkvTile;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int rt, ct;
-    const int NT = L.ld / T::BN;
-    if (!xcd_tile_map(6, NT, rt, ct)) return;
+    if (!xcd_tile_map(6, active_tiles(L), rt, ct)) return;
+    ct = global_tile(L, ct);
     const int c0 = ct * T::BN;
     const int ld = L.ld;
     const float* A = Wqkv + (size_t)rt * 128 * D;
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
     const int e = blockIdx.x * 64 + el;
     const int seg = blockIdx.y / H, h = blockIdx.y % H;
     const int frame = seg >> 1, side = seg & 1;
+    if (!((L.side_mask >> side) & 1)) return;
     const int t0 = (frame * L.np + (side ? L.n1p : 0)) / QKV_BN;
     const int nt = (side ? L.n2p : L.n1p) / QKV_BN;
     const int per = (nt + 15) / 16;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float zs[64];
     __shared__ float zpart[4][64];
-    const int ct = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const int ct = global_tile(L, blockIdx.x >> 2), h = blockIdx.x & 3;
     const int c0 = ct * T::BN, ld = L.ld;
     const TileSeg ts = tile_seg(L, c0, T::BN);
     const int src = cross ? (ts.seg ^ 1) : ts.seg;
@@ -203,9 +204,10 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
     const unsigned long long t_entry = trace ? wall_clock64() : 0;
     const unsigned long long c_entry = trace ? clock64() : 0;
     int rt, ct;
-    const int NT = L.ld / T::BN;
+    static_assert(T::BN == 64, "tile windows are counted in 64-column tiles");
     constexpr int MT = 512 / T::BM;
-    if (!xcd_tile_map(MT, NT, rt, ct)) return;
+    if (!xcd_tile_map(MT, active_tiles(L), rt, ct)) return;
+    ct = global_tile(L, ct);
     const int c0 = ct * T::BN, ld = L.ld;
     const float* A = W0 + (size_t)rt * T::BM * 512;
     f32x16 acc[T::TM][T::TN];
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restric
     const int rl = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int seg = blockIdx.x, row = blockIdx.y * 64 + rl;
     const int frame = seg >> 1, side = seg & 1;
+    if (!((L.side_mask >> side) & 1)) return;
     const int t0 = (frame * L.np + (side ? L.n1p : 0)) / MLP0_BN;
     const int nt = (side ? L.n2p : L.n1p) / MLP0_BN;
     const int n = side ? L.n2 : L.n1;
@@ -324,9 +327,10 @@ __global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ W3,
                                                    float* __restrict__ Z, ColLayout L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int rt, ct;
-    const int NT = L.ld / T::BN;
     constexpr int MT = 256 / T::BM;
-    if (!xcd_tile_map(MT, NT, rt, ct)) return;
+    constexpr int TPW = T::BN / 64;   // 64-column tiles per column tile of this kernel
+    if (!xcd_tile_map(MT, active_tiles(L) / TPW, rt, ct)) return;
+    ct = global_tile(L, ct * TPW) / TPW;
     const int c0 = ct * T::BN, ld = L.ld;
     const TileSeg ts = tile_seg(L, c0, T::BN);  // segments start on multiples of 128: a tile never straddles two
     const float* mean = stats + ((size_t)ts.seg * 2 + 0) * 512;
@@ -548,7 +552,7 @@ void allow_big_lds(K kernel, size_t = 0) {
     } while (0)
 
 void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    const int NT = w.L.ld / QkvTile::BN;
+    const int NT = active_tiles(w.L);
     GATSSPG_BIG_LDS_ONCE(qkv_kv_kernel);
     GATSSPG_LAUNCH(hk, KID_QKV_KV, s, qkv_kv_kernel, dim3(xcd_grid(6, NT)), dim3(256),
                    shaped_lds(smem_bytes<QkvTile>(), 6 * NT), s, Wqkv, bqkv, w.Z, w.Q, w.kvpart, w.L);
@@ -557,7 +561,7 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hip
 }
 
 void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook* hk) {
-    const int NT = w.L.ld / ApplyTile::BN;
+    const int NT = active_tiles(w.L);
     GATSSPG_BIG_LDS_ONCE(attn_apply_kernel);
     GATSSPG_LAUNCH(hk, KID_ATTN_APPLY, s, attn_apply_kernel, dim3(NT * H), dim3(256),
                    shaped_lds(smem_bytes<ApplyTile>(), NT * H), s, w.kvfin, w.Q, w.MSG, w.L, cross);
@@ -573,7 +577,7 @@ template <class T, int ABL = 0, bool GLDS = false>
 static void launch_mlp0_t(const float* W0, const float* b0, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     auto kern = mlp0_kernel<T, ABL, GLDS>;
     GATSSPG_BIG_LDS_ONCE(kern);
-    const int NT = w.L.ld / T::BN;
+    const int NT = active_tiles(w.L);
     GATSSPG_LAUNCH(hk, KID_MLP0, s, kern, dim3(xcd_grid(512 / T::BM, NT)), dim3(256),
                    shaped_lds(smem_bytes<T>(), 512 / T::BM * NT), s, W0, b0, w.Z, w.MSG, w.U, w.statpart, w.L, g_trace);
 }
@@ -581,7 +585,7 @@ template <class T, int ABL = 0>
 static void launch_mlp3_t(const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     auto kern = mlp3_kernel<T, ABL>;
     GATSSPG_BIG_LDS_ONCE(kern);
-    const int NT = w.L.ld / T::BN;
+    const int NT = active_tiles(w.L) / (T::BN / 64);
     GATSSPG_LAUNCH(hk, KID_MLP3, s, kern, dim3(xcd_grid(256 / T::BM, NT)), dim3(256),
                    shaped_lds(smem_bytes<T>(), 256 / T::BM * NT), s, W3, b3, w.U, w.stats, w.Z, w.L);
 }

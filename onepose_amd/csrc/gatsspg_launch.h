@@ -46,6 +46,8 @@ void launch_gats_wlt(const float* W, const float* P, const Workspace& w, int add
 
 // gatsspg_stream_kernels.hip
 void launch_load_state(const float* dq, const float* d3, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+// copies compact [b,256,n] columns of one or both sides into `dst` ([256][ld]); a null side is left untouched
+void launch_load_columns(const float* c2, const float* c3, float* dst, const Workspace& w, hipStream_t s);
 void launch_store_state(const float* src, float* out2d, float* out3d, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 void launch_gats(const float* u1, const float* u2, const float* leaves, int num_leaf, int flags, float* dst,
                  const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);

@@ -15,13 +15,14 @@ __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x)
 // state load / store    (GATs_SuperGlue.py:192-193: the .float() descriptors become the GNN state)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void load_state_kernel(const float* __restrict__ dq, const float* __restrict__ d3,
-                                                         float* __restrict__ Z, ColLayout L) {
+                                                         float* __restrict__ Z, ColLayout L, int zero_missing) {
     // one workgroup per (frame, channel) row; float4 stores (np is a multiple of 128), float4 loads when the
-    // source rows are 16-byte aligned (n1, n2 multiples of 4)
+    // source rows are 16-byte aligned (n1, n2 multiples of 4).  A null source leaves its side untouched
+    // (zero_missing = 0) or zero-fills it (zero_missing = 1).
     const int ch = blockIdx.x, f = blockIdx.y;
     float* zr = Z + (size_t)ch * L.ld + (size_t)f * L.np;
-    const float* q = dq + ((size_t)f * D + ch) * L.n1;
-    const float* y = d3 + ((size_t)f * D + ch) * L.n2;
+    const float* q = dq ? dq + ((size_t)f * D + ch) * L.n1 : nullptr;
+    const float* y = d3 ? d3 + ((size_t)f * D + ch) * L.n2 : nullptr;
     const bool vec = ((L.n1 | L.n2) & 3) == 0;
     for (int i = threadIdx.x * 4; i < L.np; i += 1024) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -29,7 +30,9 @@ __global__ __launch_bounds__(256) void load_state_kernel(const float* __restrict
         const int j = side ? i - L.n1p : i;
         const int n = side ? L.n2 : L.n1;
         const float* src = side ? y : q;
-        if (vec && j + 3 < n) {
+        if (!src) {
+            if (!zero_missing) continue;
+        } else if (vec && j + 3 < n) {
             v = *reinterpret_cast<const float4*>(src + j);
         } else {
             if (j < n) v.x = src[j];
@@ -45,14 +48,21 @@ __global__ __launch_bounds__(256) void store_state_kernel(const float* __restric
                                                           float* __restrict__ o3, ColLayout L) {
     const int ch = blockIdx.x, f = blockIdx.y;
     const float* zr = S + (size_t)ch * L.ld + (size_t)f * L.np;
-    float* q = o2 + ((size_t)f * D + ch) * L.n1;
-    float* y = o3 + ((size_t)f * D + ch) * L.n2;
-    for (int i = threadIdx.x; i < L.n1; i += 256) q[i] = zr[i];
-    for (int j = threadIdx.x; j < L.n2; j += 256) y[j] = zr[L.n1p + j];
+    if (o2) {
+        float* q = o2 + ((size_t)f * D + ch) * L.n1;
+        for (int i = threadIdx.x; i < L.n1; i += 256) q[i] = zr[i];
+    }
+    if (o3) {
+        float* y = o3 + ((size_t)f * D + ch) * L.n2;
+        for (int j = threadIdx.x; j < L.n2; j += 256) y[j] = zr[L.n1p + j];
+    }
 }
 
 void launch_load_state(const float* dq, const float* d3, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    GATSSPG_LAUNCH(hk, KID_LOAD_STATE, s, load_state_kernel, dim3(D, w.L.b), dim3(256), 0, s, dq, d3, w.Z, w.L);
+    GATSSPG_LAUNCH(hk, KID_LOAD_STATE, s, load_state_kernel, dim3(D, w.L.b), dim3(256), 0, s, dq, d3, w.Z, w.L, 1);
+}
+void launch_load_columns(const float* c2, const float* c3, float* dst, const Workspace& w, hipStream_t s) {
+    hipLaunchKernelGGL(load_state_kernel, dim3(D, w.L.b), dim3(256), 0, s, c2, c3, dst, w.L, 0);
 }
 void launch_store_state(const float* src, float* out2d, float* out3d, const Workspace& w, hipStream_t s, ProfileHook*) {
     hipLaunchKernelGGL(store_state_kernel, dim3(D, w.L.b), dim3(256), 0, s, src, out2d, out3d, w.L);

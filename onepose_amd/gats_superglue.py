@@ -132,6 +132,23 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class Database:
+    """A 3D object database kept resident on the GPU together with everything the first three GNN layers
+    derive from it alone (``GATsSuperGlue.prepare_database``).  Valid for the weights it was built with."""
+
+    def __init__(self, cache, desc3d_db, desc2d_db, b, n2, num_leaf, weights_key):
+        self.cache, self.desc3d_db, self.desc2d_db = cache, desc3d_db, desc2d_db
+        self.b, self.n2, self.num_leaf, self.weights_key = b, n2, num_leaf, weights_key
+
+    def check(self, engine, b, n2, num_leaf, device):
+        if (b, n2, num_leaf) != (self.b, self.n2, self.num_leaf) or self.cache.device != device:
+            raise ValueError(f"database cache was built for b={self.b} n2={self.n2} num_leaf={self.num_leaf} on "
+                             f"{self.cache.device}; got b={b} n2={n2} num_leaf={num_leaf} on {device}")
+        engine.packed_weights(device)
+        if engine._packed_key != self.weights_key:
+            raise ValueError("database cache was built with different weights; call prepare_database again")
+
+
 # --------------------------------------------------------------------------------------------------
 # the engine: packed weights + workspace + stage calls (also used by the per-kernel parity tests)
 # --------------------------------------------------------------------------------------------------
@@ -211,7 +228,7 @@ class GATsSPGEngine:
                 | (_native.FLAG_WITH_LINEAR_TRANSFORM if hp["with_linear_transform"] else 0))
 
     # ---- whole forward, all b samples ----
-    def forward(self, dq, d3, d2db, scale_factor, match_threshold):
+    def forward(self, dq, d3, d2db, scale_factor, match_threshold, database=None):
         b, _, n1 = dq.shape
         n2 = d3.shape[2]
         num_leaf = d2db.shape[2] // n2
@@ -223,11 +240,33 @@ class GATsSPGEngine:
         m1 = torch.empty(b, n2, device=dev, dtype=torch.int64)
         s0 = torch.empty(b, n1, device=dev, dtype=torch.float32)
         s1 = torch.empty(b, n2, device=dev, dtype=torch.float32)
+        if database is not None:
+            database.check(self, b, n2, num_leaf, dev)
+            _native.check(self.lib.gatsspg_forward_cached(
+                packed.data_ptr(), dq.data_ptr(), database.desc2d_db.data_ptr(), database.cache.data_ptr(),
+                database.cache.numel() * 4, b, n1, n2, num_leaf, self.flags(), float(scale_factor), float(match_threshold),
+                conf.data_ptr(), m0.data_ptr(), m1.data_ptr(), s0.data_ptr(), s1.data_ptr(), ws.data_ptr(), ws.numel(),
+                _stream(dev)), "gatsspg_forward_cached")
+            return conf, m0, m1, s0, s1
         _native.check(self.lib.gatsspg_forward(
             packed.data_ptr(), dq.data_ptr(), d3.data_ptr(), d2db.data_ptr(), b, n1, n2, num_leaf, self.flags(),
             float(scale_factor), float(match_threshold), conf.data_ptr(), m0.data_ptr(), m1.data_ptr(), s0.data_ptr(),
             s1.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "gatsspg_forward")
         return conf, m0, m1, s0, s1
+
+    def prepare_database(self, d3, d2db):
+        """Query-independent part of the first three GNN layers for a resident 3D database (amortised mode)."""
+        b, _, n2 = d3.shape
+        num_leaf = d2db.shape[2] // n2
+        dev = d3.device
+        packed = self.packed_weights(dev)
+        nbytes = self.lib.gatsspg_db_cache_bytes(b, n2)
+        cache = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        ws = self.workspace(b, 2, n2, num_leaf, dev)
+        _native.check(self.lib.gatsspg_prepare_database(
+            packed.data_ptr(), d3.data_ptr(), d2db.data_ptr(), b, n2, num_leaf, self.flags(), cache.data_ptr(), nbytes,
+            ws.data_ptr(), ws.numel(), _stream(dev)), "gatsspg_prepare_database")
+        return Database(cache, d3, d2db, b, n2, num_leaf, self._packed_key)
 
     # ---- stages (parity tests) ----
     def load_state(self, dq, d3, num_leaf):
@@ -313,11 +352,25 @@ class GATsSuperGlue(nn.Module):
         d3, d2db = data["descriptors3d_db"].float(), data["descriptors2d_db"].float()
         return kpts2d, kpts3d, dq, d3, d2db
 
-    def forward_batched(self, data):
+    def prepare_database(self, data):
+        """Amortised mode (not part of the reference API): keep the object's 3D database resident and precompute
+        what the first three GNN layers derive from it alone.  ``data`` needs ``descriptors3d_db`` and
+        ``descriptors2d_db``; pass the returned handle as ``database=`` to forward()/forward_batched() together
+        with the same database tensors.  Results are bit-identical to the plain forward."""
+        d3 = _require_gpu(data["descriptors3d_db"].float().contiguous(), "descriptors3d_db")
+        d2db = _require_gpu(data["descriptors2d_db"].float().contiguous(), "descriptors2d_db")
+        if d3.shape[2] < 2 or d2db.shape[2] % d3.shape[2] != 0:
+            raise ValueError("database needs >= 2 points and a whole number of leaves per point")
+        with torch.no_grad():
+            return self.engine.prepare_database(d3, d2db)
+
+    def forward_batched(self, data, database=None):
         """All b samples: returns (conf [b,n1,n2], matches0 [b,n1], matches1 [b,n2], mscores0, mscores1).
         The reference has no such path (its ``pred`` is sample 0 only); used for batched throughput."""
         if self.match_type != "softmax":
             raise NotImplementedError
+        if database is not None:
+            data = dict(data, descriptors3d_db=database.desc3d_db, descriptors2d_db=database.desc2d_db)
         _, _, dq, d3, d2db = self._inputs(data)
         dq, d3, d2db = (_require_gpu(t.contiguous(), n) for t, n in
                         ((dq, "descriptors2d_query"), (d3, "descriptors3d_db"), (d2db, "descriptors2d_db")))
@@ -329,10 +382,12 @@ class GATsSuperGlue(nn.Module):
         if d2db.shape[2] % n2 != 0 or d2db.shape[2] == 0:
             raise ValueError(f"descriptors2d_db has {d2db.shape[2]} leaves for {n2} 3D points: not a multiple")
         with torch.no_grad():
-            return self.engine.forward(dq, d3, d2db, self.hparams["scale_factor"], self.hparams["match_threshold"])
+            return self.engine.forward(dq, d3, d2db, self.hparams["scale_factor"], self.hparams["match_threshold"],
+                                       database)
 
-    def forward(self, data):
-        """Keys of ``data`` as in the reference docstring (:181-189); extra keys are ignored."""
+    def forward(self, data, database=None):
+        """Keys of ``data`` as in the reference docstring (:181-189); extra keys are ignored.  ``database``:
+        optional handle from prepare_database() (amortised mode)."""
         kpts2d, kpts3d, _, _, _ = self._inputs(data)
         if kpts2d.shape[1] == 0 or kpts3d.shape[1] == 0:  # :195-203
             shape0, shape1 = kpts2d.shape[:-1], kpts3d.shape[:-1]
@@ -345,6 +400,6 @@ class GATsSuperGlue(nn.Module):
             }
         if self.match_type != "softmax":
             raise NotImplementedError  # :238-239
-        conf, m0, m1, s0, s1 = self.forward_batched(data)
+        conf, m0, m1, s0, s1 = self.forward_batched(data, database)
         pred = {"matches0": m0[0], "matches1": m1[0], "matching_scores0": s0[0], "matching_scores1": s1[0]}
         return pred, conf

@@ -395,3 +395,42 @@ def test_lightning_style_wrapper_on_gpu(tmp_path):
     ref_pred, ref_conf = orc.forward(sd, data, dict(HP, match_threshold=0.0))
     assert maxdiff(conf.cpu().numpy(), ref_conf) < CONF_ATOL
     np.testing.assert_array_equal(pred["matches0"].cpu().numpy(), ref_pred["matches0"])
+
+
+# ----------------------------------------------------------------------------------------------------
+# amortised mode: per-object database cache
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,n2,flags_hp", [(1, 500, {}), (2, 257, {}), (1, 130, {"with_linear_transform": True, "additional": True})])
+def test_database_cache_is_bit_identical_to_plain_forward(b, n2, flags_hp):
+    """prepare_database + forward(database=...) == forward, bit for bit, for several query sizes against ONE cache."""
+    sd = synthetic.make_state_dict(8)
+    hp = dict(HP, match_threshold=0.0, **flags_hp)
+    model = make_model(sd, hp)
+    base = to_dev(synthetic.make_inputs(b, 64, n2, 8, seed=60))
+    db = model.prepare_database(base)
+    for n1, seed in ((64, 61), (200, 62), (131, 63)):
+        q = to_dev(synthetic.make_inputs(b, n1, n2, 8, seed=seed))
+        data = dict(base, descriptors2d_query=q["descriptors2d_query"], keypoints2d=q["keypoints2d"])
+        plain = model.forward_batched(data)
+        cached = model.forward_batched(data, database=db)
+        for x, y in zip(plain, cached):
+            assert torch.equal(x, y), f"n1={n1}"
+    pred_p, conf_p = model(data)
+    pred_c, conf_c = model(data, database=db)
+    assert torch.equal(conf_p, conf_c) and torch.equal(pred_p["matches0"], pred_c["matches0"])
+
+
+def test_database_cache_rejects_mismatch():
+    sd = synthetic.make_state_dict(8)
+    model = make_model(sd, HP)
+    base = to_dev(synthetic.make_inputs(1, 32, 100, 8, seed=70))
+    db = model.prepare_database(base)
+    other = to_dev(synthetic.make_inputs(1, 32, 104, 8, seed=71))
+    db_other = model.prepare_database(other)
+    with pytest.raises(ValueError, match="database cache was built for"):
+        model.engine.forward(other["descriptors2d_query"], other["descriptors3d_db"], other["descriptors2d_db"], 0.07, 0.2, db)
+    with torch.no_grad():
+        model.final_proj.bias.add_(1.0)   # weights change -> cache is stale
+    with pytest.raises(ValueError, match="different weights"):
+        model(base, database=db)
+    assert db_other is not None
