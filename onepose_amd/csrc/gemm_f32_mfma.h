@@ -234,8 +234,9 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
         }
     };
 
-    // Pipeline (prefetch distance 2): during step i the LDS buffer (i+1)&1 is free (everyone passed the
-    // barrier that ended step i-1), so slab i+1 -- loaded two steps ago into register set i&1... see below
+    // Pipeline (prefetch distance 2).  During step i the LDS buffer (i+1)&1 is free (every wave passed the
+    // barrier that ended step i-1), so slab i+1 -- sitting in register set i&1 since step i-2 -- is written
+    // there while slab i is computed from buffer i&1, and the freed registers start loading slab i+3.
     float* buf0 = smem;
     float* buf1 = smem + T::STAGE_FLOATS;
     const int last = KT - 1;
@@ -246,9 +247,9 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     __syncthreads();
     // step i (even): compute buf0; write slab i+1 (set 0) -> buf1; then reload set 0 <- slab i+3
     // step i+1 (odd): compute buf1; write slab i+2 (set 1) -> buf0; then reload set 1 <- slab i+4
-    // The write of a set precedes its reload inside a step (the reload is issued after the writes were
-    // issued; the LDS write reads its registers at issue).  Slab indices are clamped: the last loads and
-    // writes are redundant but harmless; KT is even for every GEMM here (2, 8, 16), the body is branch-free.
+    // Slab indices are clamped (the last loads / writes are redundant but harmless); KT is even for every GEMM
+    // here (2, 8, 16 slabs); the body is branch-free and the step pair is unrolled so both register sets are
+    // statically indexed (hipcc would otherwise sink the loads into a conditional block next to their use).
     const int KTL = ABLATE == 3 ? 2 : KT;
     for (int i = 0; i < KTL; i += 2) {
         step(buf0, buf1, min(i + 3, last), ra0, rb0, rx0);
