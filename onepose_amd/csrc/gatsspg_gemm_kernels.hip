@@ -539,17 +539,19 @@ static size_t shaped_lds(size_t needed, int nblocks) {
     return bytes > needed ? bytes : needed;
 }
 
-// kernels whose dynamic LDS exceeds the 64 KiB default need the limit raised once per process
+// kernels whose dynamic LDS request exceeds the 64 KiB default need the limit raised, once per device
 template <class K>
-void allow_big_lds(K kernel, size_t = 0) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024 - 2048);
+void allow_big_lds(K kernel) {
+    static bool done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - 2048);
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
 }
-#define GATSSPG_BIG_LDS_ONCE(kernel)                                  \
-    do {                                                              \
-        static const bool once_ = (allow_big_lds(kernel), true);      \
-        (void)once_;                                                  \
-    } while (0)
+#define GATSSPG_BIG_LDS_ONCE(kernel) allow_big_lds(kernel)
 
 void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     const int NT = active_tiles(w.L);
