@@ -471,3 +471,35 @@ def test_random_shapes_vs_oracle(i, b, n1, n2, L, flags):
     ref = orc.mutual_nn_match(cn, 0.0)
     np.testing.assert_array_equal(m0.cpu().numpy(), ref["matches0"])
     np.testing.assert_array_equal(m1.cpu().numpy(), ref["matches1"])
+
+
+def test_exact_ties_first_index_wins():
+    """Collisions: duplicated 3D points (same descriptor, same leaves) and duplicated query descriptors give
+    bit-identical conf columns / rows, so the row and column arg-max hit exact ties; torch.max on CPU (the
+    reference, GATs_SuperGlue.py:220-221) and numpy return the FIRST index -- so must the kernels."""
+    sd = synthetic.make_passthrough_state_dict(0)
+    b, n1, n2, L = 1, 96, 160, 8
+    data = synthetic.make_inputs(b, n1, n2, L, seed=80, planted=True)
+    # 3D point 10 duplicated at 11, 50 and 159; query 3 duplicated at 4 and 90
+    for dup in (11, 50, 159):
+        data["descriptors3d_db"][:, :, dup] = data["descriptors3d_db"][:, :, 10]
+        data["descriptors2d_db"][:, :, dup * L:(dup + 1) * L] = data["descriptors2d_db"][:, :, 10 * L:11 * L]
+    # query 3 looks at the duplicated 3D point, so its row arg-max is a 4-way exact tie (columns 10, 11, 50, 159)
+    q = data["descriptors3d_db"][0, :, 10] + 0.02 * np.random.RandomState(5).standard_normal(256).astype(np.float32)
+    data["descriptors2d_query"][0, :, 3] = q / np.linalg.norm(q)
+    for dup in (4, 90):
+        data["descriptors2d_query"][:, :, dup] = data["descriptors2d_query"][:, :, 3]
+    hp = dict(HP, match_threshold=0.0)
+    conf, m0, m1, s0, s1 = make_model(sd, hp).forward_batched(to_dev(data))
+    cn = conf.cpu().numpy()
+    assert np.array_equal(cn[0, :, 10], cn[0, :, 11]) and np.array_equal(cn[0, :, 10], cn[0, :, 159]), "duplicate columns bit-identical"
+    assert np.array_equal(cn[0, 3, :], cn[0, 4, :]) and np.array_equal(cn[0, 3, :], cn[0, 90, :]), "duplicate rows bit-identical"
+    ref = orc.mutual_nn_match(cn, 0.0)           # numpy argmax = first index, like torch.max on CPU
+    np.testing.assert_array_equal(m0.cpu().numpy(), ref["matches0"])
+    np.testing.assert_array_equal(m1.cpu().numpy(), ref["matches1"])
+    # the tie is real: some row's best column is one of the duplicates and the lowest index was chosen
+    raw0 = cn.argmax(axis=2)[0]
+    tied_rows = [i for i in range(n1) if cn[0, i, 10] == cn[0, i].max()]
+    assert tied_rows and all(raw0[i] == 10 for i in tied_rows)
+    _, conf_ref, inter = orc.forward(sd, data, hp, return_intermediates=True)
+    assert maxdiff(cn, conf_ref) < CONF_ATOL
