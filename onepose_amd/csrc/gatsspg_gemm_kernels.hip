@@ -601,6 +601,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     if (t0 == 11) launch_mlp0_t<Mlp0Tile, 1>(W0, b0, w, s, hk);        // no global loads in the loop
     else if (t0 == 12) launch_mlp0_t<Mlp0Tile, 2>(W0, b0, w, s, hk);   // no loads, no LDS writes
     else if (t0 == 15) launch_mlp0_t<Mlp0Tile, 5>(W0, b0, w, s, hk);   // all workgroups stream the same (cache-hot) panels
+    else if (t0 == 16) launch_mlp0_t<Mlp0Tile, 6>(W0, b0, w, s, hk);   // every load L1-hot
     else
 #endif
     if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);

@@ -81,7 +81,8 @@ __device__ __forceinline__ void sched_interleave_vmem() {
 }
 
 // ABLATE (profiling only, wrong results): 1 = no global loads in the steady-state loop,
-//   2 = no global loads and no LDS writes, 3 = steady-state loop cut to one step pair
+//   2 = no global loads and no LDS writes, 3 = steady-state loop cut to one step pair,
+//   6 = every load of a wave hits the same 1 KiB (always L1-hot)
 template <class T, class ASlab, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, int ABLATE = 0>
 __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
                                                  BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform) {
@@ -129,21 +130,23 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     vf4 ra0[T::A_VEC], rb0[T::B_VEC], ra1[T::A_VEC], rb1[T::B_VEC];
     float2 rx0[T::B_VEC], rx1[T::B_VEC];
 
-    auto gload = [&](int kt, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC], float2(&rx)[T::B_VEC]) {
-        const float* as = a_slab(kt);
-        const float* bs = b_slab(kt);
-#pragma unroll
-        for (int p = 0; p < T::A_VEC; ++p) ra[p] = ldg4_off(as, a_goff[p]);
-#pragma unroll
-        for (int p = 0; p < T::B_VEC; ++p) rb[p] = ldg4_off(bs, b_goff[p]);
-        if constexpr (HAS_AUX) {
-            const float* xm = x_mean(kt);
-            const float* xr = x_rstd(kt);
-#pragma unroll
-            for (int p = 0; p < T::B_VEC; ++p)
-                rx[p] = make_float2(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(xm) + x_goff[p]),
-                                    *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xr) + x_goff[p]));
+    // piece q of the staging loads of slab kt: q < A_VEC -> A piece, else B piece (+ its per-row aux)
+    constexpr int NPIECE = T::A_VEC + T::B_VEC;
+    auto gload_piece = [&](int kt, int q, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC], float2(&rx)[T::B_VEC]) {
+        const int ks = ABLATE == 6 ? 0 : kt;
+        if (q < T::A_VEC) {
+            ra[q] = ldg4_off(a_slab(ks), ABLATE == 6 ? 16u * lane : a_goff[q]);   // 6: always L1-hot (profiling)
+        } else {
+            const int p = q - T::A_VEC;
+            rb[p] = ldg4_off(b_slab(ks), ABLATE == 6 ? 16u * lane : b_goff[p]);
+            if constexpr (HAS_AUX)
+                rx[p] = make_float2(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(x_mean(kt)) + x_goff[p]),
+                                    *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x_rstd(kt)) + x_goff[p]));
         }
+    };
+    auto gload = [&](int kt, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC], float2(&rx)[T::B_VEC]) {
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) gload_piece(kt, q, ra, rb, rx);
     };
     auto swrite = [&](float* stage, const vf4(&ra)[T::A_VEC], const vf4(&rb)[T::B_VEC], const float2(&rx)[T::B_VEC]) {
 #pragma unroll
@@ -174,9 +177,9 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
 #pragma unroll
             for (int s = 0; s < 8; ++s) b[tn][s] = stage[bfrag[tn] + (h * 8 + s) * BN];
     };
-    auto mfma4 = [&](const float (&a)[TM][8], const float (&b)[TN][8], int s0) {
+    auto mfma4 = [&](const float (&a)[TM][8], const float (&b)[TN][8], int s0, int cnt = 4) {
 #pragma unroll
-        for (int s = s0; s < s0 + 4; ++s)
+        for (int s = s0; s < s0 + cnt; ++s)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -196,7 +199,7 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
             read_frags(cur, 0, a0, b0);
             read_frags(cur, 1, a1, b1);
             if constexpr (ABLATE <= 1) swrite(nxt, ra, rb, rx);
-            if constexpr (ABLATE == 0) gload(kt_load, ra, rb, rx);
+            if constexpr (ABLATE == 0 || ABLATE == 6) gload(kt_load, ra, rb, rx);
             mfma4(a0, b0, 0);
             mfma4(a0, b0, 4);
             mfma4(a1, b1, 0);
@@ -212,25 +215,37 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
             __builtin_amdgcn_sched_group_barrier(0x8, NMFMA, 0);
             __builtin_amdgcn_sched_barrier(0);
         } else {
-            // Four MFMA groups with the memory work of the step placed between them (a 32x32x2 f32 MFMA
-            // occupies the matrix pipe for 64 cycles while the wave may issue independent instructions);
-            // sched_barrier(0) between the groups keeps hipcc from regrouping them.
+            // Eight MFMA groups (2 k-steps each) with the memory work of the step placed between them (a 32x32x2
+            // f32 MFMA occupies the matrix pipe for 64 cycles while the wave may issue independent instructions);
+            // sched_barrier(0) between the groups keeps hipcc from regrouping them.  The global loads are NOT
+            // issued as one burst: measured on mlp0, loads that hit L1 are free while L1-missing ones cost ~9 %
+            // (a burst of 6 x 8 lines per wave fills the CU's miss path and the wave blocks at the load), so the
+            // pieces are spread one or two per gap over the second half of the step.
+            constexpr int GAPS = 5;                                   // gaps 3..7 carry the loads
             read_frags(cur, 0, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            mfma4(a0, b0, 0);
+            mfma4(a0, b0, 0, 2);
             __builtin_amdgcn_sched_barrier(0);
-            read_frags(cur, 1, a1, b1);
+            read_frags(cur, 1, a1, b1);                               // gap 1
             __builtin_amdgcn_sched_barrier(0);
-            mfma4(a0, b0, 4);
+            mfma4(a0, b0, 2, 2);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ABLATE <= 1) swrite(nxt, ra, rb, rx);
+            if constexpr (ABLATE <= 1 || ABLATE == 6) swrite(nxt, ra, rb, rx);   // gap 2 (frees the register set)
             __builtin_amdgcn_sched_barrier(0);
-            mfma4(a1, b1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ABLATE == 0) gload(kt_load, ra, rb, rx);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma4(a1, b1, 4);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {                             // MFMA groups 3..8, gaps 3..7 between them
+                if (g < 2) mfma4(a0, b0, 4 + 2 * g, 2);
+                else mfma4(a1, b1, 2 * (g - 2), 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g < GAPS) {
+                    if constexpr (ABLATE == 0 || ABLATE == 6) {
+#pragma unroll
+                        for (int q = 0; q < NPIECE; ++q)
+                            if (q % GAPS == g) gload_piece(kt_load, q, ra, rb, rx);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     };
 
