@@ -60,6 +60,7 @@ __device__ __forceinline__ vf4 ldg4_off(const float* base, unsigned byte_off) {
     return *reinterpret_cast<const vf4*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+
 // N x { 1 MFMA, 1 instruction of class MASK }  (LLVM SchedGroupMask: 0x8 MFMA, 0x2 VALU, 0x20 VMEM read,
 // 0x100 DS read, 0x200 DS write)
 template <int N, int MASK>

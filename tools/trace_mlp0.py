@@ -38,3 +38,11 @@ u, c = np.unique(cu, return_counts=True)
 print("blocks per CU:", dict(zip(*np.unique(c, return_counts=True))))
 one = np.isin(cu, u[c == 1])
 print(f"dur on CUs with 1 block: {np.median((end-ent)[one]):.2f} us; with 2 blocks: {np.median((end-ent)[~one]):.2f} us")
+# which operand panel do co-resident workgroups share?
+import collections
+by_cu = collections.defaultdict(list)
+for k, row in zip(cu, t):
+    by_cu[k].append((int(row[6]), int(row[7])))
+pairs = [v for v in by_cu.values() if len(v) == 2]
+same_rt = sum(1 for a, b in pairs if a[0] == b[0]); same_ct = sum(1 for a, b in pairs if a[1] == b[1])
+print(f"CUs with 2 workgroups: {len(pairs)}; same row tile (weights shared in L1): {same_rt}; same column tile: {same_ct}")
