@@ -195,8 +195,8 @@ unsigned long long* g_trace = nullptr;
 static constexpr unsigned long long* g_trace = nullptr;
 #endif
 
-template <class T, int ABL = 0, bool GLDS = false, bool WS = false>
-__global__ __launch_bounds__(WS ? 512 : 256) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
+template <class T, int ABL = 0>
+__global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                    const float* __restrict__ Z, const float* __restrict__ MSG,
                                                    float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
                                                    unsigned long long* trace) {
@@ -217,18 +217,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void mlp0_kernel(const float* __res
     const int ch0 = ABL == 5 ? 0 : c0;
     auto al = [&](int kt) { return Ah + kt * BK; };
     auto bl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : MSG + (size_t)(kt - 8) * BK * ld) + ch0; };
-    if constexpr (WS) {
-        auto nox = [](int) { return static_cast<const float*>(nullptr); };
-        if (!gemm_mainloop_ws<T, decltype(al), decltype(bl), decltype(nox), decltype(nox), NoXform, false>(
-                acc, smem, 512 / BK, al, 512, bl, ld, nox, nox, NoXform()))
-            return;   // producer waves are done
-    } else if constexpr (GLDS) {
-        auto nox = [](int) { return static_cast<const float*>(nullptr); };
-        gemm_mainloop_glds<T, decltype(al), decltype(bl), decltype(nox), decltype(nox), false>(acc, smem, 512 / BK, al, 512,
-                                                                                               bl, ld, nox, nox);
-    } else {
-        gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL)>(acc, smem, 512 / BK, al, 512, bl, ld);
-    }
+    gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL)>(acc, smem, 512 / BK, al, 512, bl, ld);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
     const unsigned long long t_loop = trace ? wall_clock64() : 0;
@@ -580,12 +569,12 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-template <class T, int ABL = 0, bool GLDS = false, bool WS = false>
+template <class T, int ABL = 0>
 static void launch_mlp0_t(const float* W0, const float* b0, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    auto kern = mlp0_kernel<T, ABL, GLDS, WS>;
+    auto kern = mlp0_kernel<T, ABL>;
     GATSSPG_BIG_LDS_ONCE(kern);
     const int NT = active_tiles(w.L);
-    GATSSPG_LAUNCH(hk, KID_MLP0, s, kern, dim3(xcd_grid(512 / T::BM, NT)), dim3(WS ? 512 : 256),
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, kern, dim3(xcd_grid(512 / T::BM, NT)), dim3(256),
                    shaped_lds(smem_bytes<T>(), 512 / T::BM * NT), s, W0, b0, w.Z, w.MSG, w.U, w.statpart, w.L, g_trace);
 }
 template <class T, int ABL = 0>
@@ -610,8 +599,6 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else
 #endif
     if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
-    else if (t0 == 2) launch_mlp0_t<Mlp0Tile, 0, true>(W0, b0, w, s, hk);   // LDS-DMA main loop
-    else if (t0 == 3) launch_mlp0_t<Mlp0Tile, 0, false, true>(W0, b0, w, s, hk);   // wave-specialised main loop
     else launch_mlp0_t<Mlp0Tile>(W0, b0, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
 #ifdef GATSSPG_PROFILING_BUILD

@@ -275,283 +275,6 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     }
 }
 
-// -------------------------------------------------------------------------------------------------------
-// Wave-specialised main loop: 512-thread workgroups, waves 0-3 are CONSUMERS (fragment reads + MFMAs, the
-// same 4-wave tile decomposition as gemm_mainloop_ex), waves 4-7 are PRODUCERS (global loads, optional
-// B transform, LDS writes).  Measured reason: L1-missing staging loads cost ~9 % because the
-// issuing wave blocks at the load in front of its own MFMAs; a producer wave that blocks costs nothing.
-// One barrier per slab, LDS double-buffered; producers prefetch one slab ahead in registers.  Returns true
-// for consumer waves; producer waves return false and the caller must make them exit (s_barrier only waits
-// for surviving waves, so later __syncthreads() of the epilogue involve the consumers alone).
-// -------------------------------------------------------------------------------------------------------
-template <class T, class ASlab, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX>
-__device__ __forceinline__ bool gemm_mainloop_ws(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
-                                                 BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform) {
-    constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN;
-#ifndef GATSSPG_WS_SLEEP
-#define GATSSPG_WS_SLEEP 10
-#endif
-    constexpr int WS_SLEEP = GATSSPG_WS_SLEEP;   // x 64 cycles
-    float* buf0 = smem;
-    float* buf1 = smem + T::STAGE_FLOATS;
-    const int last = KT - 1;
-    if (threadIdx.x >= 256) {
-        // ------------------------------ producer waves ------------------------------
-        const int tid = threadIdx.x - 256;
-        unsigned a_goff[T::A_VEC], b_goff[T::B_VEC], x_goff[T::B_VEC];
-        int a_soff[T::A_VEC], b_soff[T::B_VEC];
-#pragma unroll
-        for (int p = 0; p < T::A_VEC; ++p) {
-            const int idx = p * 256 + tid;
-            if constexpr (T::AKM) {
-                const int k = idx / (BM / 4), m = (idx % (BM / 4)) * 4;
-                a_goff[p] = 4u * (unsigned)(k * lda + m);
-                a_soff[p] = k * BM + m;
-            } else {
-                const int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
-                a_goff[p] = 4u * (unsigned)(r * lda + c);
-                a_soff[p] = r * T::A_STRIDE + c;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < T::B_VEC; ++p) {
-            const int idx = p * 256 + tid;
-            const int k = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
-            b_goff[p] = 4u * (unsigned)(k * ldb + c);
-            x_goff[p] = 4u * (unsigned)k;
-            b_soff[p] = T::A_FLOATS + k * BN + c;
-        }
-        vf4 ra[T::A_VEC], rb[T::B_VEC];
-        float2 rx[T::B_VEC];
-        auto gload = [&](int kt) {
-            const float* as = a_slab(kt);
-            const float* bs = b_slab(kt);
-#pragma unroll
-            for (int p = 0; p < T::A_VEC; ++p) ra[p] = ldg4_off(as, a_goff[p]);
-#pragma unroll
-            for (int p = 0; p < T::B_VEC; ++p) {
-                rb[p] = ldg4_off(bs, b_goff[p]);
-                if constexpr (HAS_AUX)
-                    rx[p] = make_float2(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(x_mean(kt)) + x_goff[p]),
-                                        *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x_rstd(kt)) + x_goff[p]));
-            }
-        };
-        auto swrite = [&](float* stage) {
-#pragma unroll
-            for (int p = 0; p < T::A_VEC; ++p) *reinterpret_cast<vf4*>(stage + a_soff[p]) = ra[p];
-#pragma unroll
-            for (int p = 0; p < T::B_VEC; ++p) {
-                vf4 v = rb[p];
-                if constexpr (HAS_AUX) bxform(v, rx[p]);
-                *reinterpret_cast<vf4*>(stage + b_soff[p]) = v;
-            }
-        };
-        gload(0);
-        swrite(buf0);
-        gload(min(1, last));
-        __syncthreads();
-        for (int i = 0; i < KT; ++i) {   // branch-free: the last write / load are redundant (clamped) but harmless
-            // let the consumers' fragment reads (issued right after the barrier and ~300 cycles later) go first:
-            // 24 KiB of staging writes would otherwise sit in the LDS queue in front of them
-            __builtin_amdgcn_s_sleep(WS_SLEEP);
-            swrite((i & 1) ? buf0 : buf1);          // slab i+1 into the buffer the consumers are NOT reading
-            asm volatile("" ::: "memory");
-            gload(min(i + 2, last));
-            asm volatile("" ::: "memory");
-            __syncthreads();
-        }
-        return false;
-    }
-    // ------------------------------ consumer waves ------------------------------
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / T::WN, wn = wave % T::WN;
-    const int half = lane >> 5, l31 = lane & 31;
-    int afrag[TM], bfrag[TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-        afrag[tm] = T::AKM ? (half * 16) * BM + (wm * TM + tm) * 32 + l31 : ((wm * TM + tm) * 32 + l31) * T::A_STRIDE + half * 16;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) bfrag[tn] = T::A_FLOATS + (half * 16) * BN + (wn * TN + tn) * 32 + l31;
-    auto read_frags = [&](const float* stage, int h, float (&a)[TM][8], float (&b)[TN][8]) {
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            if constexpr (T::AKM) {
-#pragma unroll
-                for (int s = 0; s < 8; ++s) a[tm][s] = stage[afrag[tm] + (h * 8 + s) * BM];
-            } else {
-                const vf4* ap = reinterpret_cast<const vf4*>(stage + afrag[tm] + h * 8);
-                const vf4 x = ap[0], y = ap[1];
-                a[tm][0] = x[0]; a[tm][1] = x[1]; a[tm][2] = x[2]; a[tm][3] = x[3];
-                a[tm][4] = y[0]; a[tm][5] = y[1]; a[tm][6] = y[2]; a[tm][7] = y[3];
-            }
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) b[tn][s] = stage[bfrag[tn] + (h * 8 + s) * BN];
-    };
-    auto mfma_n = [&](const float (&a)[TM][8], const float (&b)[TN][8], int s0, int cnt) {
-#pragma unroll
-        for (int s = s0; s < s0 + cnt; ++s)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
-    };
-    __syncthreads();
-    for (int i = 0; i < KT; ++i) {
-        const float* cur = (i & 1) ? buf1 : buf0;
-        float a0[TM][8], b0[TN][8], a1[TM][8], b1[TN][8];
-        read_frags(cur, 0, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_n(a0, b0, 0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(cur, 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_n(a0, b0, 2, 6);
-        mfma_n(a1, b1, 0, 8);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-    }
-    return true;
-}
-
-// -------------------------------------------------------------------------------------------------------
-// LDS-DMA variant of the main loop (global_load_lds_dwordx4: memory -> LDS without staging VGPRs or
-// ds_write instructions).  The DMA writes LDS lane-linearly (wave-uniform base + lane * 16 B), so
-//   * the B slab [32][BN] (already row-contiguous) is copied as is: one wave instruction = 1 KiB = 1024/(4 BN) rows;
-//   * the weight slab is stored UNPADDED as [BM][32] and the bank-conflict fix moves to the SOURCE address:
-//     physical 16-byte chunk p of row r holds logical chunk p ^ ((r >> 1) & 7); fragment reads apply the same
-//     XOR (cdna guide rule 21: linear destination + swizzled source + swizzled read).  With it the 16 rows of
-//     every ds_read_b128 lane group hit 16 distinct 16-byte slots.
-// Two LDS buffers, one slab of lookahead: the DMA of slab t+1 is issued at the top of step t (its buffer was
-// released by the barrier that ended step t-1) and drained by vmcnt(0) right before the barrier that ends
-// step t -- a full slab of MFMA time later.  Only for row-major A and GemmTiles whose A/B slabs are whole
-// numbers of 1 KiB pieces per wave.  Optional per-k (mean, rstd) transform of B is applied at fragment-read time.
-// -------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void gbl_void;
-
-template <class T, class ASlab, class BSlab, class XSlabA, class XSlabB, bool HAS_AUX>
-__device__ __forceinline__ void gemm_mainloop_glds(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
-                                                   BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd) {
-    static_assert(!T::AKM, "LDS-DMA main loop: row-major A only");
-    constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN;
-    constexpr int A_FL = BM * BK;             // unpadded
-    constexpr int B_FL = BK * BN;
-    constexpr int X_FL = HAS_AUX ? 64 : 0;    // [mean(32) | rstd(32)] per slab
-    constexpr int STAGE = A_FL + B_FL + X_FL;
-    static_assert(2 * STAGE <= T::SMEM_FLOATS, "LDS-DMA image must fit the tile's LDS allocation");
-    constexpr int A_PIECES = A_FL / 256 / 4;  // 1 KiB pieces per wave
-    constexpr int B_PIECES = B_FL / 256 / 4;
-    static_assert(A_PIECES * 4 * 256 == A_FL && B_PIECES * 4 * 256 == B_FL, "slabs must split into 1 KiB pieces per wave");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
-
-    // per-lane source byte offsets (loop invariant) and wave-uniform LDS piece offsets
-    unsigned a_goff[A_PIECES], b_goff[B_PIECES];
-#pragma unroll
-    for (int p = 0; p < A_PIECES; ++p) {
-        const int piece = wave * A_PIECES + p;          // 8 rows per piece
-        const int r = piece * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((r >> 1) & 7);  // logical chunk stored at physical chunk lane & 7
-        a_goff[p] = 4u * (unsigned)(r * lda + chunk * 4);
-    }
-#pragma unroll
-    for (int p = 0; p < B_PIECES; ++p) {
-        const int piece = wave * B_PIECES + p;          // 256 / BN rows per piece
-        const int fl = piece * 256 + lane * 4;          // float index inside the B slab image
-        b_goff[p] = 4u * (unsigned)((fl / BN) * ldb + (fl % BN));
-    }
-    auto dma = [&](int kt, float* stage) {
-        const char* as = reinterpret_cast<const char*>(a_slab(kt));
-        const char* bs = reinterpret_cast<const char*>(b_slab(kt));
-#pragma unroll
-        for (int p = 0; p < A_PIECES; ++p)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(as + a_goff[p]),
-                                             (lds_void*)(stage + (wave * A_PIECES + p) * 256), 16, 0, 0);
-#pragma unroll
-        for (int p = 0; p < B_PIECES; ++p)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(bs + b_goff[p]),
-                                             (lds_void*)(stage + A_FL + (wave * B_PIECES + p) * 256), 16, 0, 0);
-        if constexpr (HAS_AUX) {
-            if (wave == 0) {  // 64 lanes x 4 B = mean[32] | rstd[32]
-                const float* src = lane < 32 ? x_mean(kt) + lane : x_rstd(kt) + (lane - 32);
-                __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(stage + A_FL + B_FL), 4, 0, 0);
-            }
-        }
-    };
-    // fragment read offsets (floats)
-    int arow[TM], bfrag[TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) arow[tm] = (wm * TM + tm) * 32 + l31;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) bfrag[tn] = A_FL + (half * 16) * BN + (wn * TN + tn) * 32 + l31;
-
-    auto read_frags = [&](const float* stage, int h, float (&a)[TM][8], float (&b)[TN][8]) {
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int r = arow[tm];
-            const int sw = (r >> 1) & 7;
-            const int c0 = half * 4 + h * 2;   // logical chunks c0, c0 + 1
-            const vf4 x = *reinterpret_cast<const vf4*>(stage + r * BK + ((c0 ^ sw) << 2));
-            const vf4 y = *reinterpret_cast<const vf4*>(stage + r * BK + (((c0 + 1) ^ sw) << 2));
-            a[tm][0] = x[0]; a[tm][1] = x[1]; a[tm][2] = x[2]; a[tm][3] = x[3];
-            a[tm][4] = y[0]; a[tm][5] = y[1]; a[tm][6] = y[2]; a[tm][7] = y[3];
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) b[tn][s] = stage[bfrag[tn] + (h * 8 + s) * BN];
-        if constexpr (HAS_AUX) {
-            const float* xs = stage + A_FL + B_FL + half * 16 + h * 8;   // broadcast reads (uniform per lane half)
-            const vf4 m0 = *reinterpret_cast<const vf4*>(xs), m1 = *reinterpret_cast<const vf4*>(xs + 4);
-            const vf4 r0 = *reinterpret_cast<const vf4*>(xs + 32), r1 = *reinterpret_cast<const vf4*>(xs + 36);
-            const float mm[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
-            const float rr[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int s = 0; s < 8; ++s) b[tn][s] = fmaxf((b[tn][s] - mm[s]) * rr[s], 0.f);
-        }
-    };
-    auto mfma4 = [&](const float (&a)[TM][8], const float (&b)[TN][8], int s0) {
-#pragma unroll
-        for (int s = s0; s < s0 + 4; ++s)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
-    };
-
-    float* buf0 = smem;
-    float* buf1 = smem + STAGE;
-    dma(0, buf0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        float* cur = (kt & 1) ? buf1 : buf0;
-        float* nxt = (kt & 1) ? buf0 : buf1;
-        float a0[TM][8], b0[TN][8], a1[TM][8], b1[TN][8];
-        read_frags(cur, 0, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma4(a0, b0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < KT) dma(kt + 1, nxt);   // wave-uniform branch; DMA has no register results to sink
-        read_frags(cur, 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma4(a0, b0, 4);
-        mfma4(a1, b1, 0);
-        mfma4(a1, b1, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-}
-
 // convenience wrapper without per-row aux / transform
 template <class T, class ASlab, class BSlab, int ABLATE = 0>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
