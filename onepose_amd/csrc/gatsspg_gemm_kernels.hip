@@ -237,26 +237,31 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
                 Tl[row * TS + col] = v;
             }
     __syncthreads();
-    {   // 256 / BM lanes per row, each a fixed contiguous column range; combined by shuffles (fixed order)
+    {   // per-row (sum, centred sum of squares) of this tile's real columns: 256 / BM lanes per row, each a fixed
+        // contiguous column range, combined by shuffles (fixed order).  One pass, shifted by the row's first column
+        // (a pivot within a few std of the mean), so M2 = sum d^2 - (sum d)^2 / n does not cancel even when
+        // |mean| >> std; stat_final merges the tiles with Chan's formula.
         constexpr int LPR = 256 / T::BM;           // lanes per row (2 for BM=128, 1 for BM=256)
         constexpr int CPL = T::BN / LPR;           // columns per lane
         const int row = tid / LPR, part = tid % LPR;
+        const float pivot = Tl[row * TS];
         const float* tr = Tl + row * TS + part * CPL;
-        float s = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll 8
         for (int m = 0; m < CPL; ++m) {
-            const float v = (part * CPL + m < ts.valid) ? tr[m] : 0.f;
-            s += v;
-            s2 += v * v;
+            const float d = (part * CPL + m < ts.valid) ? tr[m] - pivot : 0.f;
+            s1 += d;
+            s2 += d * d;
         }
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) {
-            s += __shfl_xor(s, o);
+            s1 += __shfl_xor(s1, o);
             s2 += __shfl_xor(s2, o);
         }
         if (part == 0) {
-            statpart[((size_t)ct * 2 + 0) * 512 + rt * T::BM + row] = s;
-            statpart[((size_t)ct * 2 + 1) * 512 + rt * T::BM + row] = s2;
+            const float nv = (float)ts.valid;
+            statpart[((size_t)ct * 2 + 0) * 512 + rt * T::BM + row] = nv * pivot + s1;                       // sum
+            statpart[((size_t)ct * 2 + 1) * 512 + rt * T::BM + row] = nv > 0.f ? s2 - s1 * s1 / nv : 0.f;    // M2
         }
     }
     if (trace && tid == 0) {
@@ -268,8 +273,11 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
 }
 
 // K5  InstanceNorm statistics per (segment, channel): mean and 1/sqrt(var + 1e-5), biased variance
-//     (nn.InstanceNorm1d defaults, GATs_SuperGlue.py:126).  Partials are combined in a fixed order
-//     (64 channels x 16 tile-ranges per block, ranges combined in order) in double precision.
+//     (nn.InstanceNorm1d defaults, GATs_SuperGlue.py:126).  The per-tile partials are (sum_t, M2_t about the tile
+//     mean); with n_t real columns per tile,  M2 = sum_t M2_t + sum_t sum_t^2 / n_t - S^2 / n  (Chan's merge written
+//     out).  The cancellation-prone part is evaluated in double precision, where it is harmless, and the fp32 rounding
+//     of sum_t enters only at second order (d M2 / d sum_t = 2 (mean_t - mean)).  Fixed order: 64 channels x 16
+//     tile-ranges per block, ranges summed in tile order and combined in range order.
 __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restrict__ statpart, float* __restrict__ stats,
                                                           ColLayout L) {
     __shared__ double red[2][16][64];
@@ -282,25 +290,31 @@ __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restric
     const int n = side ? L.n2 : L.n1;
     const int per = (nt + 15) / 16;
     const int tb = part * per, te = min(nt, tb + per);
-    double s = 0.0, s2 = 0.0;
+    double S = 0.0, QP = 0.0;
 #pragma unroll 8
     for (int t = tb; t < te; ++t) {
-        s += (double)statpart[((size_t)(t0 + t) * 2 + 0) * 512 + row];
-        s2 += (double)statpart[((size_t)(t0 + t) * 2 + 1) * 512 + row];
+        const double st = (double)statpart[((size_t)(t0 + t) * 2 + 0) * 512 + row];
+        const double mt = (double)statpart[((size_t)(t0 + t) * 2 + 1) * 512 + row];
+        const int nv = min(MLP0_BN, n - t * MLP0_BN);   // real columns of tile t of this segment (<= 0: pad-only tile)
+        if (nv > 0) {
+            const double inv = nv == MLP0_BN ? 1.0 / MLP0_BN : 1.0 / nv;
+            S += st;
+            QP += mt + st * st * inv;
+        }
     }
-    red[0][part][rl] = s;
-    red[1][part][rl] = s2;
+    red[0][part][rl] = S;
+    red[1][part][rl] = QP;
     __syncthreads();
     if (part == 0) {
-        s = red[0][0][rl];
-        s2 = red[1][0][rl];
+        S = red[0][0][rl];
+        QP = red[1][0][rl];
 #pragma unroll
         for (int p = 1; p < 16; ++p) {
-            s += red[0][p][rl];
-            s2 += red[1][p][rl];
+            S += red[0][p][rl];
+            QP += red[1][p][rl];
         }
-        const double mean = s / n;
-        double var = s2 / n - mean * mean;
+        const double mean = S / n;
+        double var = (QP - S * mean) / n;
         if (var < 0.0) var = 0.0;
         stats[((size_t)seg * 2 + 0) * 512 + row] = (float)mean;
         stats[((size_t)seg * 2 + 1) * 512 + row] = (float)(1.0 / sqrt(var + 1e-5));

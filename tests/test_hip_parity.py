@@ -503,3 +503,22 @@ def test_exact_ties_first_index_wins():
     assert tied_rows and all(raw0[i] == 10 for i in tied_rows)
     _, conf_ref, inter = orc.forward(sd, data, hp, return_intermediates=True)
     assert maxdiff(cn, conf_ref) < CONF_ATOL
+
+
+def test_instance_norm_is_robust_to_large_channel_means():
+    """InstanceNorm statistics must not cancel when |mean| >> std: add a big constant to every mlp.0 bias of a layer
+    (u = 30 +- 0.2).  A sum(u^2) - n*mean^2 formulation loses ~2 % of the variance in fp32 here; the tile-centred
+    (Chan) combination does not."""
+    sd = synthetic.make_state_dict(0)
+    sd["gnn.layers.1.mlp.0.bias"] = sd["gnn.layers.1.mlp.0.bias"] + np.float32(30.0)
+    data = synthetic.make_inputs(b=1, n1=300, n2=900, num_leaf=8, seed=90)
+    model = make_model(sd, HP)
+    x, y = data["descriptors2d_query"], data["descriptors3d_db"]
+    rx = x + orc.attention_propagation(sd, "gnn.layers.1", x, x)
+    ry = y + orc.attention_propagation(sd, "gnn.layers.1", y, y)
+    eng = model.engine
+    dims = eng.load_state(torch.from_numpy(x).to(dev()), torch.from_numpy(y).to(dev()), 8)
+    eng.attn_layer(dims, 0, _native.LAYER_SELF)
+    o2, o3 = eng.store_state(dims)
+    e2, e3 = maxdiff(o2.cpu().numpy(), rx), maxdiff(o3.cpu().numpy(), ry)
+    assert e2 < 1e-4 and e3 < 1e-4, (e2, e3)
