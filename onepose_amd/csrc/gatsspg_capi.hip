@@ -42,6 +42,16 @@ int check_ws(const void* ws, size_t ws_bytes, int b, int n1, int n2, int num_lea
     return 0;
 }
 
+// The dual softmax is evaluated without max-subtraction: the scores are cosines / scale_factor, so exp() stays in range
+// as long as 1 / scale_factor <= 80 (exp(80) = 5.5e34, row sums of 1e5 terms still fit fp32).  The reference's 0.07 gives
+// 14.3.  Smaller scale factors are refused rather than silently overflowing.
+int check_scale(float scale_factor) {
+    if (!(scale_factor > 0.f)) return fail("scale_factor must be positive");
+    if (scale_factor < 0.0125f)
+        return fail("scale_factor %g is below 0.0125: exp(1/scale_factor) would overflow the fused fp32 dual softmax", scale_factor);
+    return 0;
+}
+
 int check_launch(const char* what) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("%s: %s", what, hipGetErrorString(e));
@@ -101,7 +111,7 @@ int forward_impl(const float* packed, const float* desc2d_query, const float* de
     if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
     if (!packed || !desc2d_query || !desc3d_db || !desc2d_db) return fail("null input pointer");
     if (!conf || !matches0 || !matches1 || !mscores0 || !mscores1) return fail("null output pointer");
-    if (!(scale_factor > 0.f)) return fail("scale_factor must be positive");
+    if (int e = check_scale(scale_factor)) return e;
     hipStream_t s = static_cast<hipStream_t>(stream);
     launch_load_state(desc2d_query, desc3d_db, w, s, hk);
     for (int t = 0; t < 4; ++t) {  // ['GATs', 'self', 'cross'] * 4, GATs_SuperGlue.py:162
@@ -192,7 +202,7 @@ int gatsspg_score_dual_softmax_match(int b, int n1, int n2, int num_leaf, float 
     Workspace w;
     if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
     if (!conf || !matches0 || !matches1 || !mscores0 || !mscores1) return fail("null output pointer");
-    if (!(scale_factor > 0.f)) return fail("scale_factor must be positive");
+    if (int e = check_scale(scale_factor)) return e;
     hipStream_t s = static_cast<hipStream_t>(stream);
     launch_score_exp(w, conf, scale_factor, s);
     launch_dual_softmax_match(w, conf, match_threshold, matches0, matches1, mscores0, mscores1, s);
@@ -268,7 +278,7 @@ int gatsspg_forward_cached(const float* packed, const float* desc2d_query, const
     if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
     if (!packed || !desc2d_query || !desc2d_db || !cache) return fail("null input pointer");
     if (!conf || !matches0 || !matches1 || !mscores0 || !mscores1) return fail("null output pointer");
-    if (!(scale_factor > 0.f)) return fail("scale_factor must be positive");
+    if (int e = check_scale(scale_factor)) return e;
     const DbCache c = carve_cache(const_cast<void*>(cache), b, n2);
     if (cache_bytes < c.bytes) return fail("database cache too small: %zu < %zu bytes", cache_bytes, c.bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);

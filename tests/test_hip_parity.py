@@ -522,3 +522,11 @@ def test_instance_norm_is_robust_to_large_channel_means():
     o2, o3 = eng.store_state(dims)
     e2, e3 = maxdiff(o2.cpu().numpy(), rx), maxdiff(o3.cpu().numpy(), ry)
     assert e2 < 1e-4 and e3 < 1e-4, (e2, e3)
+
+
+def test_tiny_scale_factor_is_refused_not_overflowed():
+    sd = synthetic.make_state_dict(0)
+    model = make_model(sd, dict(HP, scale_factor=0.005))
+    data = to_dev(synthetic.make_inputs(1, 16, 24, 8, seed=1))
+    with pytest.raises(_native.NativeError, match="scale_factor"):
+        model(data)
