@@ -108,3 +108,53 @@ def make_inputs(b, n1, n2, num_leaf=8, seed=1, planted=False):
         "descriptors3d_db": d3,
         "descriptors2d_db": d2db,
     }
+
+
+# ---- SuperPoint extractor (src/models/extractors/SuperPoint/superpoint.py:115-133) ---------------
+# (name, out channels, in channels, kernel size) in forward order; the state_dict holds
+# "<name>.weight" [out, in, k, k] and "<name>.bias" [out].
+SPP_LAYERS = (
+    ("conv1a", 64, 1, 3), ("conv1b", 64, 64, 3), ("conv2a", 64, 64, 3), ("conv2b", 64, 64, 3),
+    ("conv3a", 128, 64, 3), ("conv3b", 128, 128, 3), ("conv4a", 128, 128, 3), ("conv4b", 128, 128, 3),
+    ("convPa", 256, 128, 3), ("convPb", 65, 256, 1), ("convDa", 256, 128, 3), ("convDb", 256, 256, 1),
+)
+
+
+def make_spp_state_dict(seed=0, descriptor_dim=256, logit_gain=6.0):
+    """Random weights of the SuperPoint architecture.  He-normal (variance-preserving through the
+    ReLU stack) instead of PyTorch's default init, and a larger gain on the detector's last
+    conv, so that the 65-way cell softmax has a wide spread: keypoint scores then straddle the
+    0.005 threshold and NMS decisions are separated by far more than fp32 rounding."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for name, oc, ic, k in SPP_LAYERS:
+        if name == "convDb":
+            oc = descriptor_dim
+        std = np.sqrt(2.0 / (ic * k * k))
+        if name == "convPb":
+            std *= logit_gain
+        sd[f"{name}.weight"] = (rs.standard_normal((oc, ic, k, k)) * std).astype(np.float32)
+        sd[f"{name}.bias"] = (rs.standard_normal((oc,)) * 0.05).astype(np.float32)
+    return sd
+
+
+def make_image(b=1, h=512, w=512, seed=0):
+    """Synthetic grayscale image batch [b, 1, h, w] in [0, 1]: overlapping rectangles and discs on a
+    smooth gradient plus a little noise (corners and edges for the detector to respond to)."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    out = np.empty((b, 1, h, w), np.float32)
+    for i in range(b):
+        img = 0.3 + 0.2 * np.sin(xx / w * rs.uniform(2, 6)) * np.cos(yy / h * rs.uniform(2, 6))
+        for _ in range(max(4, h * w // 4096)):
+            cy, cx = rs.uniform(0, h), rs.uniform(0, w)
+            ry, rx = rs.uniform(3, h / 6), rs.uniform(3, w / 6)
+            val = rs.uniform(-0.4, 0.4)
+            if rs.rand() < 0.5:
+                m = (np.abs(yy - cy) < ry) & (np.abs(xx - cx) < rx)
+            else:
+                m = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1
+            img = img + val * m
+        img = img + rs.standard_normal((h, w)) * 0.02
+        out[i, 0] = np.clip(img, 0, 1)
+    return out
