@@ -1,4 +1,5 @@
-"""MI355X-native GATsSPG 2D-3D matcher (OnePose hot path) -- see DESIGN.md."""
+"""MI355X-native GATsSPG 2D-3D matcher (OnePose hot path) and the SuperPoint extractor in front of it -- see DESIGN.md."""
 from .gats_superglue import GATsSuperGlue, GATsSPGEngine, KeypointEncoder  # noqa: F401
+from .superpoint import SuperPoint, SuperPointEngine  # noqa: F401
 
-__all__ = ["GATsSuperGlue", "GATsSPGEngine", "KeypointEncoder"]
+__all__ = ["GATsSuperGlue", "GATsSPGEngine", "KeypointEncoder", "SuperPoint", "SuperPointEngine"]

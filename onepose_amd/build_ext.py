@@ -1,4 +1,5 @@
-"""Build libgatsspg_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""Build libgatsspg_hip.so (matcher) and libspp_hip.so (SuperPoint extractor) in-tree with hipcc for gfx950
+(cross-compiles without a GPU).
 
     python -m onepose_amd.build_ext [--force] [--remarks] [--profiling]
 """
@@ -14,6 +15,9 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgatsspg_hip.so")
 SOURCES = ["gatsspg_gemm_kernels.hip", "gatsspg_stream_kernels.hip", "gatsspg_capi.hip"]
 HEADERS = ["gatsspg_common.h", "gatsspg_launch.h", "gemm_f32_mfma.h", os.path.join("..", "..", "include", "gatsspg.h")]
+SPP_LIB_PATH = os.path.join(LIB_DIR, "libspp_hip.so")
+SPP_SOURCES = ["spp_conv_kernels.hip", "spp_detect_kernels.hip", "spp_capi.hip"]
+SPP_HEADERS = ["spp_common.h", "gemm_f32_mfma.h", "gatsspg_common.h", os.path.join("..", "..", "include", "superpoint.h")]
 
 
 def _hipcc():
@@ -23,30 +27,34 @@ def _hipcc():
     return "hipcc"
 
 
-def is_stale():
-    if not os.path.exists(LIB_PATH):
+def _stale(lib, deps):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(d) > t for d in (os.path.join(CSRC, s) for s in deps) if os.path.exists(d))
+
+
+def is_stale():
+    return _stale(LIB_PATH, SOURCES + HEADERS) or _stale(SPP_LIB_PATH, SPP_SOURCES + SPP_HEADERS)
 
 
 def build(force=False, remarks=False, verbose=True, profiling=False):
     """Compile every HIP source for gfx950 into onepose_amd/lib/libgatsspg_hip.so.
     profiling=True adds -DGATSSPG_PROFILING_BUILD (timing-only ablation variants + the mlp0 timeline hook used by
     tools/trace_mlp0.py); never ship that build."""
-    if not force and not profiling and not is_stale():
-        return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH]
-    if remarks:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    if profiling:
-        cmd.append("-DGATSSPG_PROFILING_BUILD")
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    for lib, srcs, deps in ((LIB_PATH, SOURCES, SOURCES + HEADERS), (SPP_LIB_PATH, SPP_SOURCES, SPP_SOURCES + SPP_HEADERS)):
+        if not force and not profiling and not _stale(lib, deps):
+            continue
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", lib]
+        if remarks:
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
+        if profiling:
+            cmd.append("-DGATSSPG_PROFILING_BUILD")
+        cmd += [os.path.join(CSRC, s) for s in srcs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
     return LIB_PATH
 
 

@@ -23,11 +23,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // global -> register -> LDS is forwarded by MemCpyOpt into a late global->LDS copy (load next to its use)
 typedef float vf4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ vf4 ldg4(const float* p) { return *reinterpret_cast<const vf4*>(p); }
+// same registers, but the address is only 4-byte aligned (still one global_load_dwordx4 on gfx950)
+typedef vf4 vf4u __attribute__((aligned(4)));
 
-template <int BM_, int BN_, int WM_, int WN_, bool AKM_>
+// BU_: the B slab pointers are only 4-byte aligned (column-shifted views of an activation plane, used by the
+// 3x3 convolutions of the SuperPoint extractor)
+template <int BM_, int BN_, int WM_, int WN_, bool AKM_, bool BU_ = false>
 struct GemmTile {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
-    static constexpr bool AKM = AKM_;
+    static constexpr bool AKM = AKM_, BU = BU_;
     static constexpr int TM = BM / WM / 32;   // 32x32 MFMA tiles per wave along M
     static constexpr int TN = BN / WN / 32;   // ... along N
     static constexpr int A_STRIDE = AKM ? BM : (BK + 4);
@@ -58,6 +62,9 @@ struct NoXform {
 };
 __device__ __forceinline__ vf4 ldg4_off(const float* base, unsigned byte_off) {
     return *reinterpret_cast<const vf4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ vf4 ldg4u_off(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const vf4u*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
 
@@ -139,7 +146,8 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
             ra[q] = ldg4_off(a_slab(ks), ABLATE == 6 ? 16u * lane : a_goff[q]);   // 6: always L1-hot (profiling)
         } else {
             const int p = q - T::A_VEC;
-            rb[p] = ldg4_off(b_slab(ks), ABLATE == 6 ? 16u * lane : b_goff[p]);
+            if constexpr (T::BU) rb[p] = ldg4u_off(b_slab(ks), b_goff[p]);
+            else rb[p] = ldg4_off(b_slab(ks), ABLATE == 6 ? 16u * lane : b_goff[p]);
             if constexpr (HAS_AUX)
                 rx[p] = make_float2(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(x_mean(kt)) + x_goff[p]),
                                     *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x_rstd(kt)) + x_goff[p]));

@@ -1,0 +1,220 @@
+// SuperPoint extractor, dense stages (reference: src/models/extractors/SuperPoint/superpoint.py:142-158,183-184).
+//
+//   conv1a            direct 1 -> 64 channel 3x3 (HBM-bound: one 67 MB plane set written)
+//   conv3x3 / conv1x1 implicit GEMM on the fp32 MFMA main loop of gemm_f32_mfma.h: the activation planes are
+//                     stored zero-padded and flattened (spp_common.h), so tap (dy, dx) is the same [Cin][N]
+//                     matrix shifted by dy*Wp + dx columns and the convolution is ONE GEMM with
+//                     K = taps * Cin whose B slabs are column-shifted views (4-byte aligned loads).
+//   maxpool 2x2       streaming kernel between resolutions.
+#include "gemm_f32_mfma.h"
+#include "spp_common.h"
+#include "../../include/superpoint.h"
+
+namespace spp {
+
+using gatsspg::BK;
+using gatsspg::f32x16;
+using gatsspg::GemmTile;
+using gatsspg::mfma_row;
+
+template <class T>
+constexpr size_t smem_bytes() { return sizeof(float) * T::SMEM_FLOATS; }
+
+// =====================================================================================================
+// conv1a + ReLU (:142): one thread per padded position, all 64 output channels
+// =====================================================================================================
+__global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ img, const float* __restrict__ w9,
+                                                     const float* __restrict__ bias, float* __restrict__ Y, FeatLayout L) {
+    __shared__ float sw[64 * 9 + 64];
+    for (int i = threadIdx.x; i < 64 * 9; i += 256) sw[i] = w9[i];
+    if (threadIdx.x < 64) sw[576 + threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int im = blockIdx.y;
+    if (q >= L.ld) return;
+    int y, x;
+    const bool ok = feat_valid(L, q, y, x);
+    float v[9];
+    if (ok) {
+        const float* src = img + (size_t)im * L.H * L.W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y - 1 + t / 3 - 1, xx = x - 1 + t % 3 - 1;   // pixel coordinates of the tap
+            v[t] = (yy >= 0 && yy < L.H && xx >= 0 && xx < L.W) ? src[(size_t)yy * L.W + xx] : 0.f;
+        }
+    }
+    float* dst = Y + (size_t)im * L.ld + q;
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) {
+        float a = 0.f;
+        if (ok) {
+            a = sw[576 + c];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a = fmaf(sw[c * 9 + t], v[t], a);
+            a = fmaxf(a, 0.f);
+        }
+        dst[(size_t)c * L.ldt] = a;
+    }
+}
+
+// =====================================================================================================
+// 3x3 / 1x1 convolution + bias (+ ReLU) as an implicit GEMM.  Wt [rows][TAPS*CIN] (k = tap*CIN + ci),
+// X [CIN][ldt] -> Y [cout][ldt]; pad positions of Y are written as zeros.
+// =====================================================================================================
+template <class T, int CIN, int TAPS>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                        const float* __restrict__ X, float* __restrict__ Y, FeatLayout L,
+                                                        int cout, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CPS = CIN / BK;            // K slabs per tap
+    constexpr int KT = TAPS * CPS;
+    static_assert(KT % 2 == 0, "the main loop consumes slabs in pairs");
+    const int MT = (cout + T::BM - 1) / T::BM;
+    const int NT = L.ldt / T::BN;
+    int rt, ct;
+    if (!gatsspg::xcd_tile_map(MT, NT, rt, ct)) return;
+    const int c0 = ct * T::BN, ldt = L.ldt, Wp = L.Wp;
+    const float* A = Wt + (size_t)rt * T::BM * (TAPS * CIN);
+    f32x16 acc[T::TM][T::TN];
+    gatsspg::zero_acc(acc);
+    auto al = [&](int kt) { return A + kt * BK; };
+    auto bl = [&](int kt) {
+        const int tap = kt / CPS, cc = kt - tap * CPS;
+        const int shift = TAPS == 9 ? (tap / 3 - 1) * Wp + (tap % 3 - 1) : 0;
+        return X + ((ptrdiff_t)cc * BK * ldt + c0 + shift);
+    };
+    gatsspg::gemm_mainloop<T>(acc, smem, KT, al, TAPS * CIN, bl, ldt);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int tn = 0; tn < T::TN; ++tn) {
+        const int col = c0 + (wn * T::TN + tn) * 32 + l31;
+        const int q = col % L.ld;
+        int y, x;
+        const bool ok = feat_valid(L, q, y, x);
+#pragma unroll
+        for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * T::BM + (wm * T::TM + tm) * 32 + mfma_row(r, half);
+                if (row < cout) {
+                    float v = acc[tm][tn][r] + bias[row];
+                    if (relu) v = fmaxf(v, 0.f);
+                    Y[(size_t)row * ldt + col] = ok ? v : 0.f;
+                }
+            }
+    }
+}
+
+// =====================================================================================================
+// MaxPool2d(2, 2) (:145,148,151) between padded planes; pad positions of the output are zeros
+// =====================================================================================================
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ X, FeatLayout Li, float* __restrict__ Y,
+                                                   FeatLayout Lo) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, im = blockIdx.z;
+    if (q >= Lo.ld) return;
+    int y, x;
+    float v = 0.f;
+    if (feat_valid(Lo, q, y, x)) {
+        const float* s = X + (size_t)c * Li.ldt + (size_t)im * Li.ld + (size_t)(2 * y - 1) * Li.Wp + (2 * x - 1);
+        v = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[Li.Wp], s[Li.Wp + 1]));
+    }
+    Y[(size_t)c * Lo.ldt + (size_t)im * Lo.ld + q] = v;
+}
+
+// dense descriptors out of the padded plane: [b][256][Hc][Wc]
+__global__ __launch_bounds__(256) void export_dense_kernel(const float* __restrict__ X, FeatLayout L, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, im = blockIdx.z;
+    if (i >= L.H * L.W) return;
+    const int y = i / L.W, x = i - y * L.W;
+    out[((size_t)im * DD + c) * L.H * L.W + i] = X[(size_t)c * L.ldt + (size_t)im * L.ld + (size_t)(y + 1) * L.Wp + x + 1];
+}
+
+// =====================================================================================================
+// weight packing
+// =====================================================================================================
+struct RawW {
+    const float* w[SPP_NUM_LAYERS];
+    const float* b[SPP_NUM_LAYERS];
+};
+// src [cout][cin][k][k] -> dst rows [row0, row0 + cout) of [rows][taps*cin]; rows beyond are zeroed by the caller
+__global__ void pack_conv_kernel(const float* __restrict__ src, const float* __restrict__ bsrc, float* __restrict__ dst,
+                                 float* __restrict__ bdst, int cout, int cin, int taps, int row0) {
+    const int K = taps * cin;
+    const size_t n = (size_t)cout * K;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i / K), k = (int)(i % K);
+        const int tap = k / cin, ci = k % cin;
+        dst[(size_t)(row0 + o) * K + k] = src[((size_t)o * cin + ci) * taps + tap];
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cout; i += gridDim.x * blockDim.x) bdst[row0 + i] = bsrc[i];
+}
+
+void launch_pack_weights(const void* raw_host, float* packed, hipStream_t s) {
+    const spp_raw_weights& r = *static_cast<const spp_raw_weights*>(raw_host);
+    (void)hipMemsetAsync(packed, 0, sizeof(float) * PW_TOTAL, s);
+    // conv1a: [64][1][3][3] is already [64][9]
+    (void)hipMemcpyAsync(packed + PW_C1A_W, r.weight[0], sizeof(float) * 64 * 9, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(packed + PW_C1A_B, r.bias[0], sizeof(float) * 64, hipMemcpyDeviceToDevice, s);
+    auto pack = [&](int gi, int layer, int row0) {
+        const ConvSpec c = kConv[gi];
+        const int cout = layer == 9 ? 65 : (gi == 7 ? 256 : c.cout);
+        hipLaunchKernelGGL(pack_conv_kernel, dim3(256), dim3(256), 0, s, r.weight[layer], r.bias[layer], packed + conv_w_off(gi),
+                           packed + conv_b_off(gi), cout, c.cin, c.taps, row0);
+    };
+    for (int gi = 0; gi < 7; ++gi) pack(gi, gi + 1, 0);   // conv1b .. conv4b
+    pack(7, 8, 0);      // convPa
+    pack(7, 10, 256);   // convDa
+    pack(8, 9, 0);      // convPb
+    pack(9, 11, 0);     // convDb
+}
+
+// =====================================================================================================
+// launchers
+// =====================================================================================================
+using Tile64x128 = GemmTile<64, 128, 1, 4, false, true>;
+using Tile64x64 = GemmTile<64, 64, 2, 2, false, true>;
+using Tile128x64 = GemmTile<128, 64, 2, 2, false, true>;
+
+template <class T, int CIN, int TAPS>
+static void launch_conv(int gi, int kid, const float* packed, const float* X, float* Y, const FeatLayout& L, int relu,
+                        hipStream_t s, ProfileHook* hk) {
+    auto kern = conv_gemm_kernel<T, CIN, TAPS>;
+    const int cout = kConv[gi].cout;
+    const int MT = (cout + T::BM - 1) / T::BM, NT = L.ldt / T::BN;
+    SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(MT, NT)), dim3(256), smem_bytes<T>(), s, packed + conv_w_off(gi),
+               packed + conv_b_off(gi), X, Y, L, cout, relu);
+}
+
+static void launch_pool(const float* X, const FeatLayout& Li, float* Y, const FeatLayout& Lo, int C, hipStream_t s,
+                        ProfileHook* hk) {
+    SPP_LAUNCH(hk, KID_POOL, s, pool_kernel, dim3((Lo.ld + 255) / 256, C, Lo.b), dim3(256), 0, s, X, Li, Y, Lo);
+}
+
+void launch_dense(const float* packed, const float* image, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    SPP_LAUNCH(hk, KID_CONV1A, s, conv1a_kernel, dim3((w.L1.ld + 255) / 256, w.L1.b), dim3(256), 0, s, image,
+               packed + PW_C1A_W, packed + PW_C1A_B, w.a1, w.L1);
+    launch_conv<Tile64x128, 64, 9>(0, KID_CONV1B, packed, w.a1, w.b1, w.L1, 1, s, hk);
+    launch_pool(w.b1, w.L1, w.a2, w.L2, 64, s, hk);
+    launch_conv<Tile64x128, 64, 9>(1, KID_CONV2, packed, w.a2, w.b2, w.L2, 1, s, hk);
+    launch_conv<Tile64x128, 64, 9>(2, KID_CONV2, packed, w.b2, w.a2, w.L2, 1, s, hk);
+    launch_pool(w.a2, w.L2, w.a3, w.L3, 64, s, hk);
+    launch_conv<Tile64x64, 64, 9>(3, KID_CONV3A, packed, w.a3, w.b3, w.L3, 1, s, hk);
+    launch_conv<Tile64x64, 128, 9>(4, KID_CONV3B, packed, w.b3, w.c3, w.L3, 1, s, hk);
+    launch_pool(w.c3, w.L3, w.a4, w.L4, 128, s, hk);
+    launch_conv<Tile64x64, 128, 9>(5, KID_CONV4, packed, w.a4, w.b4, w.L4, 1, s, hk);
+    launch_conv<Tile64x64, 128, 9>(6, KID_CONV4, packed, w.b4, w.a4, w.L4, 1, s, hk);
+    launch_conv<Tile64x64, 128, 9>(7, KID_HEADS, packed, w.a4, w.hd, w.L4, 1, s, hk);                      // relu(convPa), relu(convDa)
+    launch_conv<Tile64x64, 256, 1>(8, KID_CONVPB, packed, w.hd, w.lg, w.L4, 0, s, hk);                     // logits
+    launch_conv<Tile64x64, 256, 1>(9, KID_CONVDB, packed, w.hd + (size_t)256 * w.L4.ldt, w.dd, w.L4, 0, s, hk);   // descriptors
+}
+
+void launch_export_dense(const Workspace& w, float* dense_desc, hipStream_t s) {
+    hipLaunchKernelGGL(export_dense_kernel, dim3((w.L4.H * w.L4.W + 255) / 256, DD, w.L4.b), dim3(256), 0, s, w.dd, w.L4,
+                       dense_desc);
+}
+
+}  // namespace spp

@@ -1,0 +1,393 @@
+// SuperPoint extractor, detector / descriptor heads after the convolutions
+// (reference: src/models/extractors/SuperPoint/superpoint.py:47-94,158-195).
+//
+// Every step that decides WHICH pixels become keypoints (exact float equality in the NMS, threshold, border,
+// top-k) is integer / comparison work on one fp32 score map and is reproduced bit for bit: given the same score
+// map the keypoint list is identical to the reference's (tests feed the oracle's map through spp_detect).
+#include "spp_common.h"
+
+namespace spp {
+
+// =====================================================================================================
+// softmax over the 65 cell channels, dustbin dropped, 8x8 cell shuffle (:158-162)
+//   LG [65(+pad)][ldt] padded 1/8-resolution plane -> score [b][H][W]
+// =====================================================================================================
+__global__ __launch_bounds__(64) void score_map_kernel(const float* __restrict__ LG, FeatLayout Lc, float* __restrict__ score) {
+    const int cell = blockIdx.x * 64 + threadIdx.x;
+    const int im = blockIdx.y;
+    if (cell >= Lc.H * Lc.W) return;
+    const int cy = cell / Lc.W, cx = cell - cy * Lc.W;
+    const float* src = LG + (size_t)im * Lc.ld + (size_t)(cy + 1) * Lc.Wp + cx + 1;
+    float l[65];
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 65; ++r) {
+        l[r] = src[(size_t)r * Lc.ldt];
+        m = fmaxf(m, l[r]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 65; ++r) {
+        l[r] = expf(l[r] - m);
+        sum += l[r];
+    }
+    const int W = Lc.W * 8;
+    float* dst = score + (size_t)im * Lc.H * 8 * W + (size_t)cy * 8 * W + cx * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float4 lo = make_float4(l[i * 8 + 0] / sum, l[i * 8 + 1] / sum, l[i * 8 + 2] / sum, l[i * 8 + 3] / sum);
+        float4 hi = make_float4(l[i * 8 + 4] / sum, l[i * 8 + 5] / sum, l[i * 8 + 6] / sum, l[i * 8 + 7] / sum);
+        *reinterpret_cast<float4*>(dst + (size_t)i * W) = lo;
+        *reinterpret_cast<float4*>(dst + (size_t)i * W + 4) = hi;
+    }
+}
+
+// =====================================================================================================
+// simple_nms (:47-62), all five max-pools of the two suppression rounds inside one workgroup: a T x T output tile
+// with a 5*R halo (the dependency radius of the final mask) lives in LDS; max-pools are separable.
+// Out-of-image taps are -inf exactly as max_pool2d pads.
+// =====================================================================================================
+constexpr int E = NMS_E;
+struct NmsSmem {
+    float s[E * E], ss[E * E], t[E * E];
+    unsigned char m[E * E], sup[E * E], tb[E * E];
+};
+
+__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ score, float* __restrict__ out, int H, int W, int R,
+                                                  int T) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nms_raw[];
+    NmsSmem& S = *reinterpret_cast<NmsSmem*>(nms_raw);
+    const int im = blockIdx.z;
+    const int y0 = blockIdx.y * T - 5 * R, x0 = blockIdx.x * T - 5 * R;   // region origin in the image
+    const float* src = score + (size_t)im * H * W;
+    const int tid = threadIdx.x;
+    const float NINF = -INFINITY;
+    auto inside = [&](int i) {
+        const int y = y0 + i / E, x = x0 + i % E;
+        return y >= 0 && y < H && x >= 0 && x < W;
+    };
+    for (int i = tid; i < E * E; i += 256) {
+        const int y = y0 + i / E, x = x0 + i % E;
+        S.s[i] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : NINF;
+    }
+    __syncthreads();
+    // separable (2R+1)^2 max over the region (taps outside the region are skipped: they only influence
+    // positions further than the halo from the tile)
+    auto pool_f = [&](const float* in, float* outp) {
+        for (int i = tid; i < E * E; i += 256) {
+            const int r = i / E, c = i % E;
+            float v = NINF;
+            for (int d = -R; d <= R; ++d) {
+                const int cc = c + d;
+                if (cc >= 0 && cc < E) v = fmaxf(v, in[r * E + cc]);
+            }
+            S.t[i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < E * E; i += 256) {
+            const int r = i / E, c = i % E;
+            float v = NINF;
+            for (int d = -R; d <= R; ++d) {
+                const int rr = r + d;
+                if (rr >= 0 && rr < E) v = fmaxf(v, S.t[rr * E + c]);
+            }
+            outp[i] = v;
+        }
+        __syncthreads();
+    };
+    auto pool_b = [&](const unsigned char* in, unsigned char* outp) {
+        for (int i = tid; i < E * E; i += 256) {
+            const int r = i / E, c = i % E;
+            unsigned char v = 0;
+            for (int d = -R; d <= R; ++d) {
+                const int cc = c + d;
+                if (cc >= 0 && cc < E) v |= in[r * E + cc];
+            }
+            S.tb[i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < E * E; i += 256) {
+            const int r = i / E, c = i % E;
+            unsigned char v = 0;
+            for (int d = -R; d <= R; ++d) {
+                const int rr = r + d;
+                if (rr >= 0 && rr < E) v |= S.tb[rr * E + c];
+            }
+            outp[i] = v;
+        }
+        __syncthreads();
+    };
+    // max_mask = scores == max_pool(scores)                                        (:56)
+    pool_f(S.s, S.ss);
+    for (int i = tid; i < E * E; i += 256) S.m[i] = inside(i) && S.s[i] == S.ss[i];
+    __syncthreads();
+    for (int it = 0; it < 2; ++it) {                                                 // (:57-61)
+        pool_b(S.m, S.sup);                                                           // supp_mask = max_pool(max_mask) > 0
+        for (int i = tid; i < E * E; i += 256) S.ss[i] = inside(i) ? (S.sup[i] ? 0.f : S.s[i]) : NINF;   // supp_scores
+        __syncthreads();
+        // new_max_mask = supp_scores == max_pool(supp_scores): pooled values go to a register per element
+        // (the row pass writes S.t, the column pass is consumed immediately)
+        for (int i = tid; i < E * E; i += 256) {
+            const int r = i / E, c = i % E;
+            float v = NINF;
+            for (int d = -R; d <= R; ++d) {
+                const int cc = c + d;
+                if (cc >= 0 && cc < E) v = fmaxf(v, S.ss[r * E + cc]);
+            }
+            S.t[i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < E * E; i += 256) {
+            const int r = i / E, c = i % E;
+            float v = NINF;
+            for (int d = -R; d <= R; ++d) {
+                const int rr = r + d;
+                if (rr >= 0 && rr < E) v = fmaxf(v, S.t[rr * E + c]);
+            }
+            const bool nw = inside(i) && S.ss[i] == v;
+            S.m[i] = S.m[i] | (nw && !S.sup[i]);                                      // max_mask | (new & ~supp)
+        }
+        __syncthreads();
+    }
+    float* dst = out + (size_t)im * H * W;
+    for (int i = tid; i < T * T; i += 256) {
+        const int ty = i / T, tx = i % T;
+        const int y = blockIdx.y * T + ty, x = blockIdx.x * T + tx;
+        if (y < H && x < W) {
+            const int j = (ty + 5 * R) * E + tx + 5 * R;
+            dst[(size_t)y * W + x] = S.m[j] ? S.s[j] : 0.f;                            // (:62)
+        }
+    }
+}
+
+// =====================================================================================================
+// keypoint list in row-major (torch.nonzero) order: threshold (:165-167) and border (:65-70) tests,
+// per-row counts -> exclusive scan -> ordered compaction
+// =====================================================================================================
+__device__ __forceinline__ bool is_keypoint(float v, int y, int x, int H, int W, float thr, int border) {
+    return v > thr && y >= border && y < H - border && x >= border && x < W - border;
+}
+
+__global__ __launch_bounds__(64) void rowcount_kernel(const float* __restrict__ nms, int H, int W, float thr, int border,
+                                                      int* __restrict__ rowcnt) {
+    const int y = blockIdx.x, im = blockIdx.y, lane = threadIdx.x;
+    const float* row = nms + ((size_t)im * H + y) * W;
+    int cnt = 0;
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        const bool p = x < W && is_keypoint(row[x < W ? x : 0], y, x, H, W, thr, border);
+        cnt += __popcll(__ballot(p));
+    }
+    if (lane == 0) rowcnt[im * H + y] = cnt;
+}
+
+__global__ __launch_bounds__(1024) void rowscan_kernel(const int* __restrict__ rowcnt, int H, int* __restrict__ rowoff,
+                                                       int* __restrict__ ncand) {
+    __shared__ int part[1024];
+    const int im = blockIdx.x, tid = threadIdx.x;
+    const int per = (H + 1023) / 1024;
+    int local = 0;
+    for (int k = 0; k < per; ++k) {
+        const int y = tid * per + k;
+        if (y < H) local += rowcnt[im * H + y];
+    }
+    part[tid] = local;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {      // Hillis-Steele inclusive scan (integers: order-independent)
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - local;
+    for (int k = 0; k < per; ++k) {
+        const int y = tid * per + k;
+        if (y < H) {
+            rowoff[im * H + y] = run;
+            run += rowcnt[im * H + y];
+        }
+    }
+    if (tid == 1023) ncand[im] = part[1023];
+}
+
+__global__ __launch_bounds__(64) void compact_kernel(const float* __restrict__ nms, int H, int W, float thr, int border,
+                                                     const int* __restrict__ rowoff, int* __restrict__ cand) {
+    const int y = blockIdx.x, im = blockIdx.y, lane = threadIdx.x;
+    const float* row = nms + ((size_t)im * H + y) * W;
+    int base = rowoff[im * H + y];
+    int* dst = cand + (size_t)im * H * W;
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        const bool p = x < W && is_keypoint(row[x < W ? x : 0], y, x, H, W, thr, border);
+        const unsigned long long mask = __ballot(p);
+        if (p) dst[base + __popcll(mask & ((1ull << lane) - 1ull))] = y * W + x;
+        base += __popcll(mask);
+    }
+}
+
+// =====================================================================================================
+// top_k_keypoints (:73-78) as a rank sort: rank_i = #{j : s_j > s_i or (s_j == s_i and j < i)}; candidate i goes to
+// slot rank_i when rank_i < k.  Deterministic, no cross-workgroup communication.  With n <= k (or k = -1) the
+// row-major list is kept as is.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ nms, int HW, const int* __restrict__ ncand,
+                                                     const int* __restrict__ cand, int max_kp, int capacity,
+                                                     int* __restrict__ sel, int32_t* __restrict__ counts) {
+    __shared__ float sj[256];
+    const int im = blockIdx.y, tid = threadIdx.x;
+    const int n = ncand[im];
+    const bool topk = max_kp >= 0 && n > max_kp;
+    const int nout = topk ? max_kp : (n < capacity ? n : capacity);
+    if (blockIdx.x == 0 && tid == 0) {
+        counts[im * 2 + 0] = nout;
+        counts[im * 2 + 1] = n;
+    }
+    if (blockIdx.x * 256 >= n) return;
+    const int i = blockIdx.x * 256 + tid;
+    const int* c = cand + (size_t)im * HW;
+    int* o = sel + (size_t)im * HW;
+    const float* sc = nms + (size_t)im * HW;
+    if (!topk) {
+        if (i < nout) o[i] = c[i];
+        return;
+    }
+    const float si = i < n ? sc[c[i]] : 0.f;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        __syncthreads();
+        sj[tid] = (j0 + tid < n) ? sc[c[j0 + tid]] : -1.f;    // scores are > threshold >= ... > -1: never counted
+        __syncthreads();
+        const int lim = min(256, n - j0);
+        for (int j = 0; j < lim; ++j) {
+            const float v = sj[j];
+            rank += (v > si) || (v == si && j0 + j < i);
+        }
+    }
+    if (i < n && rank < max_kp) o[rank] = c[i];
+}
+
+// =====================================================================================================
+// descriptors: 1 / max(||d||, eps) per cell (:185), then per keypoint bilinear sampling of the normalised
+// map and a second normalisation (:81-94).  One workgroup = 64 keypoints x 256 channels.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void cellnorm_kernel(DescView dv, int Hc, int Wc, float* __restrict__ invn) {
+    const int cell = blockIdx.x * 256 + threadIdx.x, im = blockIdx.y;
+    if (cell >= Hc * Wc) return;
+    const int cy = cell / Wc, cx = cell - cy * Wc;
+    const float* p = dv.p + (size_t)im * dv.istride + dv.origin + (size_t)cy * dv.rstride + cx;
+    float ss = 0.f;
+    for (int c = 0; c < DD; ++c) {
+        const float v = p[(size_t)c * dv.cstride];
+        ss = fmaf(v, v, ss);
+    }
+    invn[(size_t)im * Hc * Wc + cell] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(DescView dv, int Hc, int Wc, const float* __restrict__ invn,
+                                                     const float* __restrict__ nms, const int* __restrict__ sel,
+                                                     const int32_t* __restrict__ counts, int H, int W, int align_corners,
+                                                     int capacity, float* __restrict__ keypoints, float* __restrict__ scores,
+                                                     float* __restrict__ desc) {
+    __shared__ float part[4][64];
+    const int im = blockIdx.y, tid = threadIdx.x;
+    const int kl = tid & 63, grp = tid >> 6;
+    const int slot = blockIdx.x * 64 + kl;
+    const int nout = counts[im * 2];
+    if (blockIdx.x * 64 >= nout) return;
+    const bool live = slot < nout;
+    int pix = 0;
+    if (live) pix = sel[(size_t)im * H * W + slot];
+    const int py = pix / W, px = pix - py * W;
+    // sample_descriptors (:83-88) with s = 8: keypoints - s/2 + 0.5, / (w*s - s/2 - 0.5), *2 - 1
+    const float kx = (float)px - 4.f + 0.5f, ky = (float)py - 4.f + 0.5f;
+    const float gx = kx / ((float)(Wc * 8) - 4.f - 0.5f) * 2.f - 1.f;
+    const float gy = ky / ((float)(Hc * 8) - 4.f - 0.5f) * 2.f - 1.f;
+    float ix, iy;
+    if (align_corners) {
+        ix = (gx + 1.f) / 2.f * (float)(Wc - 1);
+        iy = (gy + 1.f) / 2.f * (float)(Hc - 1);
+    } else {
+        ix = ((gx + 1.f) * (float)Wc - 1.f) / 2.f;
+        iy = ((gy + 1.f) * (float)Hc - 1.f) / 2.f;
+    }
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    float wq[4];
+    int off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int xi = x0 + (q & 1), yi = y0 + (q >> 1);
+        const bool ok = live && xi >= 0 && xi < Wc && yi >= 0 && yi < Hc;
+        const float w = (1.f - fabsf(ix - (float)xi)) * (1.f - fabsf(iy - (float)yi));
+        const int cell = ok ? yi * Wc + xi : 0;
+        wq[q] = ok ? w * invn[(size_t)im * Hc * Wc + cell] : 0.f;
+        off[q] = ok ? yi * dv.rstride + xi : 0;
+    }
+    const float* base = dv.p + (size_t)im * dv.istride + dv.origin;
+    float v[64];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        const float* pc = base + (size_t)(grp * 64 + k) * dv.cstride;
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a = fmaf(pc[off[q]], wq[q], a);
+        v[k] = a;
+        ss = fmaf(a, a, ss);
+    }
+    part[grp][kl] = ss;
+    __syncthreads();
+    const float tot = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
+    const float inv = 1.f / fmaxf(sqrtf(tot), 1e-12f);
+    if (!live) return;
+    float* d = desc + (size_t)im * DD * capacity + slot;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) d[(size_t)(grp * 64 + k) * capacity] = v[k] * inv;
+    if (grp == 0) {
+        keypoints[((size_t)im * capacity + slot) * 2 + 0] = (float)px;     // (:180) (h, w) -> (x, y)
+        keypoints[((size_t)im * capacity + slot) * 2 + 1] = (float)py;
+        scores[(size_t)im * capacity + slot] = nms[(size_t)im * H * W + pix];
+    }
+}
+
+// =====================================================================================================
+// launchers
+// =====================================================================================================
+void launch_score_map(const Workspace& w, float* score_map, hipStream_t s, ProfileHook* hk) {
+    const int cells = w.L4.H * w.L4.W;
+    SPP_LAUNCH(hk, KID_SCORE, s, score_map_kernel, dim3((cells + 63) / 64, w.L4.b), dim3(64), 0, s, w.lg, w.L4, score_map);
+}
+
+void launch_detect(const float* score_map, DescView dv, const Workspace& w, const DetectParams& dp, float* keypoints,
+                   float* scores, float* descriptors, int32_t* counts, float* nms_out, hipStream_t s, ProfileHook* hk) {
+    const int b = w.L1.b, H = w.L1.H, W = w.L1.W, Hc = w.L4.H, Wc = w.L4.W;
+    float* nms = nms_out ? nms_out : w.nms;
+    const int R = dp.nms_radius;
+    if (R == 0) {
+        (void)hipMemcpyAsync(nms, score_map, sizeof(float) * (size_t)b * H * W, hipMemcpyDeviceToDevice, s);   // :62 with an all-true mask
+    } else {
+        static bool attr_done[16] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 16 && !attr_done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)sizeof(NmsSmem));
+            attr_done[dev] = true;
+        }
+        const int T = E - 10 * R < 32 ? E - 10 * R : 32;
+        SPP_LAUNCH(hk, KID_NMS, s, nms_kernel, dim3((W + T - 1) / T, (H + T - 1) / T, b), dim3(256), sizeof(NmsSmem), s,
+                   score_map, nms, H, W, R, T);
+    }
+    SPP_LAUNCH(hk, KID_ROWCOUNT, s, rowcount_kernel, dim3(H, b), dim3(64), 0, s, nms, H, W, dp.threshold, dp.remove_borders,
+               w.rowcnt);
+    SPP_LAUNCH(hk, KID_SCAN, s, rowscan_kernel, dim3(b), dim3(1024), 0, s, w.rowcnt, H, w.rowoff, w.ncand);
+    SPP_LAUNCH(hk, KID_COMPACT, s, compact_kernel, dim3(H, b), dim3(64), 0, s, nms, H, W, dp.threshold, dp.remove_borders,
+               w.rowoff, w.cand);
+    SPP_LAUNCH(hk, KID_SELECT, s, select_kernel, dim3((H * W + 255) / 256, b), dim3(256), 0, s, nms, H * W, w.ncand, w.cand,
+               dp.max_keypoints, dp.capacity, w.sel, counts);
+    SPP_LAUNCH(hk, KID_CELLNORM, s, cellnorm_kernel, dim3((Hc * Wc + 255) / 256, b), dim3(256), 0, s, dv, Hc, Wc, w.invn);
+    SPP_LAUNCH(hk, KID_SAMPLE, s, sample_kernel, dim3((dp.capacity + 63) / 64, b), dim3(256), 0, s, dv, Hc, Wc, w.invn, nms,
+               w.sel, counts, H, W, dp.align_corners, dp.capacity, keypoints, scores, descriptors);
+}
+
+}  // namespace spp

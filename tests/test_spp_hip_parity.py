@@ -1,0 +1,251 @@
+"""GPU parity of the HIP SuperPoint extractor (through the C ABI of include/superpoint.h) against the numpy
+oracle and the reference goldens.  Tolerances:
+
+* dense stages (convolutions, softmax): fp32 re-association only -> score map 1e-5 abs, descriptors 1e-5 abs;
+* discrete stages (NMS equality tests, threshold, border, top-k, ordering): BIT-EXACT given the same score map
+  (the oracle's map is fed through spp_detect);
+* end to end: the same keypoint set as the reference on the goldens.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from onepose_amd import synthetic  # noqa: E402
+from oracle import superpoint_oracle as so  # noqa: E402
+
+with open(os.path.join(GOLDEN_DIR, "spp_golden_meta.json")) as f:
+    META = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+
+ATOL_SCORE = 1e-5
+ATOL_DESC = 1e-5
+
+
+def golden(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, f"spp_{name}.npz")))
+
+
+def make_module(wseed, cfg, align=True):
+    from onepose_amd import SuperPoint
+    m = SuperPoint(dict(cfg), align_corners=align)
+    sd = synthetic.make_spp_state_dict(wseed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.cuda().eval(), sd
+
+
+def match_rows(kp, gk):
+    key = lambda a: (a[:, 1].astype(np.int64) << 20) | a[:, 0].astype(np.int64)
+    ka, kb = key(kp), key(gk)
+    oa, ob = np.argsort(ka), np.argsort(kb)
+    assert np.array_equal(ka[oa], kb[ob]), "keypoint sets differ"
+    p = np.empty(len(gk), np.int64)
+    p[ob] = oa
+    return p
+
+
+@pytest.mark.parametrize("name", ["tiny_default", "rect_pipeline", "r0_thr"])
+def test_dense_stages_vs_oracle_and_golden(name):
+    m = META[name]
+    mod, sd = make_module(m["wseed"], m["cfg"])
+    img = synthetic.make_image(**m["img"])
+    score, dense = mod.engine.dense(torch.from_numpy(img).cuda())
+    score, dense = score.cpu().numpy(), dense.cpu().numpy()
+    g = golden(name)
+    for i in range(m["img"]["b"]):
+        feat = so.encoder(sd, img[i, 0])
+        np.testing.assert_allclose(score[i], so.score_map(sd, feat), atol=ATOL_SCORE)
+        raw = g["dense_raw"][i]
+        np.testing.assert_allclose(dense[i], raw, atol=2e-5 * np.abs(raw).max())
+        lg = g["logits"][i]
+        e = np.exp(lg - lg.max(axis=0, keepdims=True))
+        p = (e / e.sum(axis=0, keepdims=True))[:-1]
+        h, w = p.shape[1:]
+        ref_map = p.transpose(1, 2, 0).reshape(h, w, 8, 8).transpose(0, 2, 1, 3).reshape(h * 8, w * 8)
+        np.testing.assert_allclose(score[i], ref_map, atol=ATOL_SCORE)
+
+
+DETECT_CASES = [
+    # (h, w, radius, threshold, border, max_kp, seed)
+    (64, 64, 4, 0.005, 4, -1, 0),
+    (120, 160, 3, 0.005, 4, 4096, 1),
+    (96, 96, 2, 0.005, 4, 50, 2),
+    (64, 80, 0, 0.05, 0, -1, 3),
+    (72, 200, 1, 0.01, 2, 300, 4),
+    (136, 104, 5, 0.002, 8, -1, 5),
+    (64, 64, 6, 0.0, 0, 7, 6),
+    (256, 256, 3, 0.005, 4, 1000, 7),
+]
+
+
+@pytest.mark.parametrize("h,w,radius,thr,border,max_kp,seed", DETECT_CASES)
+def test_detect_bit_exact_on_oracle_score_map(h, w, radius, thr, border, max_kp, seed):
+    """Same fp32 score map in -> identical NMS map, identical keypoint list (order included), identical scores."""
+    cfg = {"nms_radius": radius, "keypoint_threshold": thr, "remove_borders": border, "max_keypoints": max_kp}
+    mod, sd = make_module(seed, cfg)
+    img = synthetic.make_image(1, h, w, seed + 100)
+    feat = so.encoder(sd, img[0, 0])
+    sm = so.score_map(sd, feat)
+    raw = so.conv2d(so.relu(so.conv2d(feat, sd["convDa.weight"], sd["convDa.bias"])), sd["convDb.weight"], sd["convDb.bias"])
+    full_cfg = {**so.DEFAULT_CONFIG, **cfg}
+    kp, sc, de, cnt, nms = mod.engine.detect(torch.from_numpy(sm[None]).cuda(), torch.from_numpy(raw[None]).cuda(), full_cfg,
+                                             True, return_nms=True)
+    ref_nms = so.simple_nms(sm, radius)
+    np.testing.assert_array_equal(nms[0].cpu().numpy(), ref_nms)
+    yx, rsc = so.select_keypoints(ref_nms, thr, border, max_kp)
+    n = int(cnt[0, 0])
+    assert n == len(yx)
+    np.testing.assert_array_equal(kp[0, :n].cpu().numpy(), yx[:, ::-1].astype(np.float32))
+    np.testing.assert_array_equal(sc[0, :n].cpu().numpy(), rsc)
+    dense = so.dense_descriptors(sd, feat)
+    rde = so.sample_descriptors(yx[:, ::-1].astype(np.float32), dense, 8, True)
+    np.testing.assert_allclose(de[0, :, :n].cpu().numpy(), rde, atol=2e-6)
+    np.testing.assert_allclose(np.linalg.norm(de[0, :, :n].cpu().numpy(), axis=0), 1.0, atol=1e-5)
+
+
+def test_detect_ties_and_plateaus():
+    """Exactly equal scores: top-k keeps the lower row-major index first; plateaus survive the NMS as in the reference."""
+    h = w = 64
+    cfg = {**so.DEFAULT_CONFIG, "nms_radius": 2, "remove_borders": 0, "max_keypoints": 5}
+    mod, _ = make_module(0, cfg)
+    sm = np.zeros((h, w), np.float32)
+    for (y, x) in [(5, 5), (5, 40), (20, 9), (33, 33), (50, 12), (60, 60), (10, 25)]:
+        sm[y, x] = 0.5                      # seven exactly equal isolated maxima
+    sm[40, 40] = 0.9
+    sm[30:33, 50:53] = 0.25                 # a 3x3 plateau: every pixel equals its window maximum
+    raw = np.random.RandomState(0).standard_normal((256, 8, 8)).astype(np.float32)
+    for max_kp in (5, -1):
+        cfg["max_keypoints"] = max_kp
+        kp, sc, de, cnt, nms = mod.engine.detect(torch.from_numpy(sm[None]).cuda(), torch.from_numpy(raw[None]).cuda(), cfg,
+                                                 True, return_nms=True)
+        ref_nms = so.simple_nms(sm, 2)
+        np.testing.assert_array_equal(nms[0].cpu().numpy(), ref_nms)
+        yx, rsc = so.select_keypoints(ref_nms, cfg["keypoint_threshold"], 0, max_kp)
+        n = int(cnt[0, 0])
+        assert n == len(yx) and int(cnt[0, 1]) == 17
+        np.testing.assert_array_equal(kp[0, :n].cpu().numpy(), yx[:, ::-1].astype(np.float32))
+        np.testing.assert_array_equal(sc[0, :n].cpu().numpy(), rsc)
+    assert n == 17
+
+
+@pytest.mark.parametrize("name", ["tiny_default", "rect_pipeline", "rect_noalign", "r0_thr", "topk50"])
+def test_forward_vs_reference_golden(name):
+    m = META[name]
+    mod, _ = make_module(m["wseed"], m["cfg"], align=m["align"])
+    out = mod(torch.from_numpy(synthetic.make_image(**m["img"])).cuda())
+    g = golden(name)
+    for i in range(m["img"]["b"]):
+        kp, sc, de = (out[k][i].cpu().numpy() for k in ("keypoints", "scores", "descriptors"))
+        gk, gs, gd = g[f"keypoints{i}"], g[f"scores{i}"], g[f"descriptors{i}"]
+        assert kp.dtype == np.float32 and kp.shape == gk.shape and de.shape == gd.shape
+        if name == "topk50":
+            p = match_rows(kp, gk)
+            assert np.all(np.diff(sc) <= 0)
+        else:
+            np.testing.assert_array_equal(kp, gk)           # same keypoints in the same (row-major) order
+            p = np.arange(len(gk))
+        np.testing.assert_allclose(sc[p], gs, atol=ATOL_SCORE)
+        np.testing.assert_allclose(de[:, p], gd, atol=ATOL_DESC)
+
+
+def test_forward_crop512_vs_golden_and_oracle():
+    """The pipeline's shape (512x512, radius 3, top 4096)."""
+    m = META["crop512"]
+    mod, sd = make_module(m["wseed"], m["cfg"])
+    img = synthetic.make_image(**m["img"])
+    out = mod(torch.from_numpy(img).cuda())
+    kp, sc, de = (out[k][0].cpu().numpy() for k in ("keypoints", "scores", "descriptors"))
+    g = golden("crop512")
+    gk, gs = g["keypoints0"], g["scores0"]
+    assert len(kp) == 4096 and np.all(np.diff(sc) <= 0)
+    # top-k cut: candidates whose score is within fp32 noise of the 4096th may legitimately swap
+    a = set(map(tuple, kp.astype(np.int64).tolist()))
+    b = set(map(tuple, gk.astype(np.int64).tolist()))
+    cut = gs.min()
+    swapped = [(x, y) for (x, y) in a ^ b]
+    assert len(swapped) <= 8, f"{len(swapped)} keypoints differ from the reference"
+    common = np.array(sorted(a & b), np.float32)
+    ia = {t: i for i, t in enumerate(map(tuple, kp.astype(np.int64).tolist()))}
+    ib = {t: i for i, t in enumerate(map(tuple, gk.astype(np.int64).tolist()))}
+    idx_a = np.array([ia[tuple(t)] for t in common.astype(np.int64).tolist()])
+    idx_b = np.array([ib[tuple(t)] for t in common.astype(np.int64).tolist()])
+    np.testing.assert_allclose(sc[idx_a], gs[idx_b], atol=ATOL_SCORE)
+    for t in swapped:
+        s = sc[ia[t]] if t in ia else gs[ib[t]]
+        assert abs(s - cut) < 1e-5
+    sub = idx_b % 8 == 0
+    np.testing.assert_allclose(de[:, idx_a[sub]], g["descriptors0_every8"][:, idx_b[sub] // 8], atol=ATOL_DESC)
+    logits_sub = g["logits_every4"]
+    assert logits_sub.shape == (1, 65, 16, 16)
+
+
+def test_forward_device_batched_and_determinism():
+    cfg = {"nms_radius": 3, "max_keypoints": 512}
+    mod, _ = make_module(3, cfg)
+    img = torch.from_numpy(synthetic.make_image(3, 128, 160, 9)).cuda()
+    kp, sc, de, cnt = mod.forward_device(img)
+    kp2, sc2, de2, cnt2 = mod.forward_device(img)
+    assert torch.equal(cnt, cnt2)
+    for i in range(3):
+        n = int(cnt[i, 0])
+        assert torch.equal(kp[i, :n], kp2[i, :n]) and torch.equal(sc[i, :n], sc2[i, :n]) and torch.equal(de[i, :, :n], de2[i, :, :n])
+        single = mod(img[i:i + 1])
+        assert torch.equal(single["keypoints"][0], kp[i, :n])          # batching does not change a frame's result
+        assert torch.equal(single["descriptors"][0], de[i, :, :n])
+
+
+def test_keep_all_overflow(monkeypatch):
+    """max_keypoints=-1 with more candidates than the output capacity: the C ABI reports both counts and writes the
+    first `capacity` keypoints in row-major order; the module re-runs with room for all."""
+    cfg = {**so.DEFAULT_CONFIG, "nms_radius": 1, "keypoint_threshold": 0.0, "remove_borders": 0, "max_keypoints": -1}
+    mod, sd = make_module(1, cfg)
+    img = synthetic.make_image(1, 64, 64, 2)
+    ref = so.forward(sd, img, cfg)
+    nref = len(ref["keypoints"][0])
+    assert nref > 100
+    kp, sc, de, cnt = mod.engine.forward(torch.from_numpy(img).cuda(), cfg, True, capacity=100)
+    assert cnt.cpu().tolist() == [[100, nref]]
+    np.testing.assert_array_equal(kp[0].cpu().numpy(), ref["keypoints"][0][:100])
+    real = mod.engine._capacity
+    monkeypatch.setattr(mod.engine, "_capacity", lambda c, h, w, cap: real(c, h, w, cap) if cap is not None else 100)
+    out = mod(torch.from_numpy(img).cuda())
+    np.testing.assert_array_equal(out["keypoints"][0].cpu().numpy(), ref["keypoints"][0])
+
+
+def test_extractor_feeds_matcher_on_device():
+    """inference.py:140-146 without the GPU->CPU->GPU round trip: descriptors go straight into the matcher."""
+    from onepose_amd import GATsSuperGlue
+    mod, _ = make_module(0, {"nms_radius": 3, "max_keypoints": 300})
+    det = mod(torch.from_numpy(synthetic.make_image(1, 256, 256, 4)).cuda())
+    n1 = det["keypoints"][0].shape[0]
+    assert n1 == 300
+    hp = {"descriptor_dim": 256, "keypoints_encoder": [32, 64, 128], "match_type": "softmax", "scale_factor": 0.07,
+          "match_threshold": 0.2, "include_self": True, "additional": False, "with_linear_transform": False}
+    matcher = GATsSuperGlue(hp)
+    matcher.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(0).items()}, strict=True)
+    matcher = matcher.cuda().eval()
+    data = synthetic.make_inputs(b=1, n1=n1, n2=500, num_leaf=8, seed=1)
+    inp = {k: torch.from_numpy(v).cuda() for k, v in data.items()}
+    inp["descriptors2d_query"] = det["descriptors"][0][None].contiguous()
+    inp["keypoints2d"] = det["keypoints"][0][None]
+    pred, conf = matcher(inp)
+    assert conf.shape == (1, n1, 500) and pred["matches0"].shape == (n1,)
+    assert torch.isfinite(conf).all()
+
+
+def test_bad_arguments_raise():
+    from onepose_amd._native import NativeError
+    mod, _ = make_module(0, {})
+    with pytest.raises(NativeError, match="multiples of 8"):
+        mod(torch.zeros(1, 1, 60, 64).cuda())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mod(torch.zeros(1, 1, 64, 64))
+    mod.config["nms_radius"] = 9
+    with pytest.raises(NativeError, match="nms_radius"):
+        mod(torch.zeros(1, 1, 64, 64).cuda())
