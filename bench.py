@@ -17,6 +17,15 @@ The JSON line also carries
                  events recorded on the compute stream around one of its launches in every timed step;
   cpu_baseline : the numpy oracle (a port of the reference algorithm) timed on this host's cores on a
                  bounded sample of the same workload (rank 0, N=1 only).
+
+    python bench.py --extractor [...]   the SuperPoint extractor in front of the matcher: one step =
+                                        one 512x512 grayscale crop -> keypoints, scores, descriptors, all in HBM
+                                        (same JSON contract, metric extractor_images_per_sec; never the headline value)
+    python bench.py --pipeline [...]    image -> extractor -> matcher with nothing leaving HBM (inference.py:140-146 without
+                                        the GPU->CPU->GPU round trip of pack_data); informative
+    python bench.py [--extractor] --torch-eager   the same ALGORITHM through stock PyTorch-ROCm ops on this GPU (the
+                                        oracle/torch_* restatements: one ATen / rocBLAS / MIOpen launch per op, like the
+                                        reference modules) -- an informative baseline line, no HIP kernels of this repo
 """
 import argparse
 import json
@@ -30,7 +39,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from onepose_amd import GATsSuperGlue, _native, sharding, synthetic  # noqa: E402
+from onepose_amd import GATsSuperGlue, SuperPoint, _native, _native_spp, sharding, synthetic  # noqa: E402
 
 N1, N2, NUM_LEAF, D = 1000, 7000, 8, 256
 HP = {"descriptor_dim": 256, "keypoints_encoder": [32, 64, 128], "match_type": "softmax", "scale_factor": 0.07,
@@ -138,27 +147,255 @@ def pmc_traffic(kernel):
         return None
 
 
-def cpu_baseline(max_seconds=30.0):
-    """The oracle (numpy port of the reference algorithm) on this host, headline shape, batch 1."""
-    from oracle import gatsspg_oracle as orc
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:  # noqa: BLE001
-        threads = os.cpu_count()
-    sd = synthetic.make_state_dict(0)
-    data = synthetic.make_inputs(1, N1, N2, NUM_LEAF, seed=1)
+def cpu_baseline(max_seconds=20.0):
+    """The reference algorithm on this host's cores, headline shape, batch 1: oracle/torch_oracle.py, i.e. the same stock
+    PyTorch CPU ops (conv1d, einsum, InstanceNorm1d, softmax) the reference module executes -- the faster of the two oracle
+    restatements (the literal numpy one, oracle/gatsspg_oracle.py, runs at about a quarter of this rate)."""
+    from oracle import gatsspg_oracle, torch_oracle
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(0).items()}
+    data = {k: torch.from_numpy(v) for k, v in synthetic.make_inputs(1, N1, N2, NUM_LEAF, seed=1).items()}
+    hp = dict(gatsspg_oracle.DEFAULT_HPARAMS)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        torch_oracle.forward(sd, data, hp)  # warm-up (also bounds the sample)
+        warm = time.perf_counter() - t0
+        n = max(1, min(10, int(max_seconds / max(warm, 1e-3)) - 1))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            torch_oracle.forward(sd, data, hp)
+        dt = (time.perf_counter() - t0) / n
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{n} frame(s) after 1 warm-up, N_2D={N1} N_3D={N2} num_leaf={NUM_LEAF} batch 1 fp32, stock PyTorch CPU ops "
+                      f"restating GATsSuperGlue.forward incl. the literal h@W GEMMs (oracle/torch_oracle.py), {dt * 1e3:.0f} ms/frame"}
+
+
+# =====================================================================================================
+# SuperPoint extractor mode (--extractor)
+# =====================================================================================================
+SPP_H = SPP_W = 512                                                            # src/sfm/extract_features.py:15-19
+SPP_CFG = {"descriptor_dim": 256, "nms_radius": 3, "max_keypoints": 4096}      # :21-26 (keypoint_threshold stays 0.005)
+SPP_CONVS = (  # (name, cout, cin, taps, resolution divisor)
+    ("conv1a", 64, 1, 9, 1), ("conv1b", 64, 64, 9, 1), ("conv2a", 64, 64, 9, 2), ("conv2b", 64, 64, 9, 2),
+    ("conv3a", 128, 64, 9, 4), ("conv3b", 128, 128, 9, 4), ("conv4a", 128, 128, 9, 8), ("conv4b", 128, 128, 9, 8),
+    ("convPa", 256, 128, 9, 8), ("convPb", 65, 256, 1, 8), ("convDa", 256, 128, 9, 8), ("convDb", 256, 256, 1, 8))
+
+
+def spp_flops(h, w, only=None):
+    """Algorithmic flops of the convolutions on the real pixels (2 * cout * cin * taps * H * W per layer)."""
+    tot = 0
+    for name, co, ci, taps, div in SPP_CONVS:
+        f = 2 * co * ci * taps * (h // div) * (w // div)
+        if only is None or name in only:
+            tot += f
+    return tot
+
+
+SPP_KERNEL_LAYERS = {"conv1b": ("conv1b",), "conv2": ("conv2a",), "conv3a": ("conv3a",), "conv3b": ("conv3b",),
+                     "conv4": ("conv4a",), "heads": ("convPa", "convDa"), "convPb": ("convPb",), "convDb": ("convDb",)}
+
+
+class SppRunner:
+    """One in-flight image slot of the extractor: own stream, workspace and outputs; step() = one spp_forward call."""
+
+    def __init__(self, device, model, images, own_stream=False, b=1):
+        self.lib = model.engine.lib
+        self.packed = model.engine.packed_weights(device)
+        self.cfg = model.config
+        self.images = images
+        self.b = b
+        self.cap = self.cfg["max_keypoints"]
+        self.ws = torch.empty(self.lib.spp_workspace_bytes(b, SPP_H, SPP_W), device=device, dtype=torch.uint8)
+        self.kp = torch.empty(b, self.cap, 2, device=device)
+        self.sc = torch.empty(b, self.cap, device=device)
+        self.de = torch.empty(b, 256, self.cap, device=device)
+        self.cnt = torch.zeros(b, 2, device=device, dtype=torch.int32)
+        self.stream = torch.cuda.Stream(device) if own_stream else torch.cuda.current_stream(device)
+
+    def _args(self, i):
+        c = self.cfg
+        return (self.packed.data_ptr(), self.images[i % len(self.images)].data_ptr(), self.b, SPP_H, SPP_W, c["nms_radius"],
+                c["keypoint_threshold"], c["max_keypoints"], c["remove_borders"], 1, self.cap, self.kp.data_ptr(),
+                self.sc.data_ptr(), self.de.data_ptr(), self.cnt.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                self.stream.cuda_stream)
+
+    def step(self, i):
+        _native_spp.check(self.lib.spp_forward(*self._args(i)), "spp_forward")
+
+    def step_profiled(self, i, kernel, ev0, ev1):
+        _native_spp.check(self.lib.spp_forward_profiled(*self._args(i), _native_spp.KERNEL_IDS[kernel], 0, ev0.cuda_event,
+                                                        ev1.cuda_event), "spp_forward_profiled")
+
+
+def spp_cpu_baseline(max_seconds=20.0):
+    """The reference algorithm on this host's cores: oracle/torch_superpoint_oracle.py, i.e. the same stock PyTorch CPU
+    ops (MKL-DNN convolutions, max_pool2d, grid_sample) the reference module executes, full 512x512 image."""
+    from oracle import torch_superpoint_oracle as tso
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_spp_state_dict(0).items()}
+    img = torch.from_numpy(synthetic.make_image(1, SPP_H, SPP_W, 11))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        tso.forward(sd, img, SPP_CFG)
+        warm = time.perf_counter() - t0
+        n = max(1, min(10, int(max_seconds / max(warm, 1e-3)) - 1))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tso.forward(sd, img, SPP_CFG)
+        dt = (time.perf_counter() - t0) / n
+    return {"value": round(1.0 / dt, 3), "unit": "images/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{n} image(s) {SPP_H}x{SPP_W} after 1 warm-up, stock PyTorch CPU ops restating SuperPoint.forward "
+                      f"(oracle/torch_superpoint_oracle.py), {dt * 1e3:.0f} ms/image"}
+
+
+def main_extractor(args):
+    rank, local_rank, world = sharding.init_process_group()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    model = SuperPoint(SPP_CFG)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_spp_state_dict(0).items()}, strict=True)
+    model = model.to(device).eval()
+    images = [torch.from_numpy(synthetic.make_image(1, SPP_H, SPP_W, 11 + i)).to(device) for i in range(4)]
+    K, W, S = args.steps, args.warmup, max(1, args.streams)
+    slots = [SppRunner(device, model, images, own_stream=True) for _ in range(S)]
+    torch.cuda.synchronize(device)
+    for i in range(W):
+        slots[i % S].step(i)
+    torch.cuda.synchronize(device)
+    sharding.barrier()
+    torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    orc.forward(sd, data, HP)  # warm-up (also bounds the sample)
-    warm = time.perf_counter() - t0
-    n = max(1, min(3, int(max_seconds / max(warm, 1e-3)) - 1))
+    for i in range(K):
+        slots[i % S].step(i)
+    torch.cuda.synchronize(device)
+    sharding.barrier()
+    elapsed = time.perf_counter() - t0
+
+    runner = slots[0]
+    kernel = args.spp_kernel
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    with torch.cuda.stream(runner.stream):
+        for e0, e1 in events:
+            e0.record(runner.stream)
+            e1.record(runner.stream)
+        for i in range(W):
+            runner.step(i)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for i in range(K):
+            runner.step_profiled(i, kernel, events[i][0], events[i][1])
+        torch.cuda.synchronize(device)
+        latency = (time.perf_counter() - t1) / K
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+    n_kp = int(runner.cnt[0, 0])
+
+    per_rank = sharding.gather_metrics([K, elapsed], device=device)
+    value, seconds = sharding.aggregate_throughput(per_rank.cpu())
+    if rank == 0:
+        fl = spp_flops(SPP_H, SPP_W, SPP_KERNEL_LAYERS[kernel])
+        achieved = fl / (kern_ms * 1e-3) / 1e12
+        total = spp_flops(SPP_H, SPP_W)
+        out = {
+            "metric": "extractor_images_per_sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": round(seconds / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"SuperPoint extractor (SURVEY 8(f) row 2), one synthetic {SPP_H}x{SPP_W} grayscale crop per step, "
+                                   "pipeline config nms_radius=3 max_keypoints=4096 threshold=0.005, fp32, random weights",
+                       "images_in_flight_per_gpu": S, "single_image_latency_ms": round(latency * 1e3, 4),
+                       "keypoints_out": n_kp, "algorithmic_gflop_per_image": round(total / 1e9, 2),
+                       "end_to_end_f32_mfma_frac": round(total * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "roofline": {"bound": "mfma", "kernel": f"conv_gemm_kernel ({kernel})", "achieved": round(achieved, 2),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": pmc_traffic("spp_" + kernel), "kernel_ms": round(kern_ms, 5), "flops_per_launch": fl,
+                         "how": f"hipEvent pair on the compute stream around launch #0 of the {kernel} convolution in each of {K} "
+                                "steps of a one-image-at-a-time pass"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = spp_cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def main_torch_eager(args):
+    """Informative baseline: the reference algorithm via stock PyTorch-ROCm eager ops on this GPU."""
+    dev = torch.device("cuda", 0)
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    iters = max(5, min(args.steps, 50))
+    if args.extractor:
+        from oracle import torch_superpoint_oracle as tso
+        sd = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_spp_state_dict(0).items()}
+        img = torch.from_numpy(synthetic.make_image(1, SPP_H, SPP_W, 11)).to(dev)
+        fn = lambda: tso.forward(sd, img, SPP_CFG)
+        unit, what = "images/s", f"SuperPoint {SPP_H}x{SPP_W}"
+    else:
+        from oracle import gatsspg_oracle, torch_oracle
+        sd = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_state_dict(0).items()}
+        data = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_inputs(1, N1, N2, NUM_LEAF, seed=1).items()}
+        hp = dict(gatsspg_oracle.DEFAULT_HPARAMS)
+        fn = lambda: torch_oracle.forward(sd, data, hp)
+        unit, what = "frames/s", f"GATsSPG N_2D={N1} N_3D={N2}"
+    with torch.no_grad():
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    print(json.dumps({"baseline": "reference algorithm via stock PyTorch-ROCm eager ops on this GPU", "workload": what,
+                      "torch": torch.__version__, "dtype": "f32", "iters": iters, "ms_per_step": round(dt * 1e3, 3),
+                      "value": round(1 / dt, 2), "unit": unit}), flush=True)
+
+
+def main_pipeline(args):
+    """image -> SuperPoint -> GATsSPG on one stream, descriptors handed over inside HBM (no host round trip; the
+    matcher runs on all max_keypoints slots -- the synthetic image fills them)."""
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    model = SuperPoint({**SPP_CFG, "max_keypoints": N1})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_spp_state_dict(0).items()}, strict=True)
+    model = model.to(device).eval()
+    images = [torch.from_numpy(synthetic.make_image(1, SPP_H, SPP_W, 11 + i)).to(device) for i in range(4)]
+    weights = Weights(device)
+    K, W, S = args.steps, args.warmup, max(1, args.streams)
+    base = Runner(device, weights)
+    slots = []
+    for _ in range(S):
+        sp = SppRunner(device, model, images, own_stream=True)
+        mt = Runner(device, weights, base.shared_inputs, own_stream=False)
+        mt.stream = sp.stream
+        mt.queries = [sp.de]                      # [1, 256, N1] written by the extractor, read by the matcher
+        slots.append((sp, mt))
+
+    def step(i):
+        sp, mt = slots[i % S]
+        sp.step(i)
+        mt.step(i)
+
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize(device)
+    assert int(slots[0][0].cnt[0, 0]) == N1, "the synthetic image must fill all keypoint slots"
     t0 = time.perf_counter()
-    for _ in range(n):
-        orc.forward(sd, data, HP)
-    dt = (time.perf_counter() - t0) / n
-    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n} frame(s) after 1 warm-up, N_2D={N1} N_3D={N2} num_leaf={NUM_LEAF} batch 1 fp32, numpy oracle "
-                      f"(literal reference algorithm incl. the h@W GEMMs), {dt * 1e3:.0f} ms/frame"}
+    for i in range(K):
+        step(i)
+    torch.cuda.synchronize(device)
+    thr = K / (time.perf_counter() - t0)
+    S1 = slots[:1]
+    t0 = time.perf_counter()
+    for i in range(K):
+        S1[0][0].step(i)
+        S1[0][1].step(i)
+    torch.cuda.synchronize(device)
+    lat = (time.perf_counter() - t0) / K
+    print(json.dumps({"metric": "pipeline_frames_per_sec", "value": round(thr, 2), "unit": "frames/s", "n_gpus": 1, "steps": K,
+                      "warmup": W, "ms_per_step": round(1e3 / thr, 4), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": f"{SPP_H}x{SPP_W} crop -> SuperPoint (top {N1}) -> GATsSPG vs N_3D={N2} database, "
+                                             "batch 1, all hand-offs in HBM", "frames_in_flight": S,
+                                 "single_frame_latency_ms": round(lat * 1e3, 4)}}), flush=True)
 
 
 def main():
@@ -172,7 +409,18 @@ def main():
                          "precomputed once per object); informative, never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default=DOMINANT, choices=list(_native.KERNEL_IDS))
+    ap.add_argument("--extractor", action="store_true", help="benchmark the SuperPoint extractor instead of the matcher")
+    ap.add_argument("--spp-kernel", default="conv1b", choices=list(SPP_KERNEL_LAYERS))
+    ap.add_argument("--pipeline", action="store_true", help="image -> extractor -> matcher, all hand-offs in HBM (informative)")
+    ap.add_argument("--torch-eager", action="store_true",
+                    help="informative baseline: the reference algorithm through stock PyTorch-ROCm ops on this GPU")
     args = ap.parse_args()
+    if args.torch_eager:
+        return main_torch_eager(args)
+    if args.pipeline:
+        return main_pipeline(args)
+    if args.extractor:
+        return main_extractor(args)
 
     rank, local_rank, world = sharding.init_process_group()
     if world != args.gpus:

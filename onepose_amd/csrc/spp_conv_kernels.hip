@@ -6,6 +6,8 @@
 //                     matrix shifted by dy*Wp + dx columns and the convolution is ONE GEMM with
 //                     K = taps * Cin whose B slabs are column-shifted views (4-byte aligned loads).
 //   maxpool 2x2       streaming kernel between resolutions.
+#include <stdlib.h>
+
 #include "gemm_f32_mfma.h"
 #include "spp_common.h"
 #include "../../include/superpoint.h"
@@ -136,10 +138,6 @@ __global__ __launch_bounds__(256) void export_dense_kernel(const float* __restri
 // =====================================================================================================
 // weight packing
 // =====================================================================================================
-struct RawW {
-    const float* w[SPP_NUM_LAYERS];
-    const float* b[SPP_NUM_LAYERS];
-};
 // src [cout][cin][k][k] -> dst rows [row0, row0 + cout) of [rows][taps*cin]; rows beyond are zeroed by the caller
 __global__ void pack_conv_kernel(const float* __restrict__ src, const float* __restrict__ bsrc, float* __restrict__ dst,
                                  float* __restrict__ bdst, int cout, int cin, int taps, int row0) {
@@ -180,13 +178,41 @@ using Tile64x64 = GemmTile<64, 64, 2, 2, false, true>;
 using Tile128x64 = GemmTile<128, 64, 2, 2, false, true>;
 
 template <class T, int CIN, int TAPS>
-static void launch_conv(int gi, int kid, const float* packed, const float* X, float* Y, const FeatLayout& L, int relu,
-                        hipStream_t s, ProfileHook* hk) {
+static void launch_conv_t(int gi, int kid, const float* packed, const float* X, float* Y, const FeatLayout& L, int relu,
+                          hipStream_t s, ProfileHook* hk) {
     auto kern = conv_gemm_kernel<T, CIN, TAPS>;
     const int cout = kConv[gi].cout;
     const int MT = (cout + T::BM - 1) / T::BM, NT = L.ldt / T::BN;
     SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(MT, NT)), dim3(256), smem_bytes<T>(), s, packed + conv_w_off(gi),
                packed + conv_b_off(gi), X, Y, L, cout, relu);
+}
+
+// Tile shape per GEMM convolution: 0 = 64x128, 1 = 64x64, 2 = 128x64 (rows x columns).  SPP_TILES="a,b,..." (ten
+// comma-separated ids, forward order conv1b..convDb) overrides the defaults for tuning; every choice is equally correct.
+static const int* conv_tiles() {
+    static int tiles[NGEMM] = {0, 0, 0, 1, 1, 1, 1, 1, 1, 1};
+    static bool init = false;
+    if (!init) {
+        init = true;
+        if (const char* e = getenv("SPP_TILES")) {
+            int i = 0;
+            for (const char* p = e; *p && i < NGEMM; ++p)
+                if (*p >= '0' && *p <= '2') tiles[i++] = *p - '0';
+        }
+        for (int i = 0; i < NGEMM; ++i)
+            if (tiles[i] == 2 && kConv[i].rows % 128) tiles[i] = 1;
+    }
+    return tiles;
+}
+
+template <int CIN, int TAPS>
+static void launch_conv(int gi, int kid, const float* packed, const float* X, float* Y, const FeatLayout& L, int relu,
+                        hipStream_t s, ProfileHook* hk) {
+    switch (conv_tiles()[gi]) {
+        case 0: launch_conv_t<Tile64x128, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+        case 2: launch_conv_t<Tile128x64, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+        default: launch_conv_t<Tile64x64, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+    }
 }
 
 static void launch_pool(const float* X, const FeatLayout& Li, float* Y, const FeatLayout& Lo, int C, hipStream_t s,
@@ -197,19 +223,19 @@ static void launch_pool(const float* X, const FeatLayout& Li, float* Y, const Fe
 void launch_dense(const float* packed, const float* image, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     SPP_LAUNCH(hk, KID_CONV1A, s, conv1a_kernel, dim3((w.L1.ld + 255) / 256, w.L1.b), dim3(256), 0, s, image,
                packed + PW_C1A_W, packed + PW_C1A_B, w.a1, w.L1);
-    launch_conv<Tile64x128, 64, 9>(0, KID_CONV1B, packed, w.a1, w.b1, w.L1, 1, s, hk);
+    launch_conv<64, 9>(0, KID_CONV1B, packed, w.a1, w.b1, w.L1, 1, s, hk);
     launch_pool(w.b1, w.L1, w.a2, w.L2, 64, s, hk);
-    launch_conv<Tile64x128, 64, 9>(1, KID_CONV2, packed, w.a2, w.b2, w.L2, 1, s, hk);
-    launch_conv<Tile64x128, 64, 9>(2, KID_CONV2, packed, w.b2, w.a2, w.L2, 1, s, hk);
+    launch_conv<64, 9>(1, KID_CONV2, packed, w.a2, w.b2, w.L2, 1, s, hk);
+    launch_conv<64, 9>(2, KID_CONV2, packed, w.b2, w.a2, w.L2, 1, s, hk);
     launch_pool(w.a2, w.L2, w.a3, w.L3, 64, s, hk);
-    launch_conv<Tile64x64, 64, 9>(3, KID_CONV3A, packed, w.a3, w.b3, w.L3, 1, s, hk);
-    launch_conv<Tile64x64, 128, 9>(4, KID_CONV3B, packed, w.b3, w.c3, w.L3, 1, s, hk);
+    launch_conv<64, 9>(3, KID_CONV3A, packed, w.a3, w.b3, w.L3, 1, s, hk);
+    launch_conv<128, 9>(4, KID_CONV3B, packed, w.b3, w.c3, w.L3, 1, s, hk);
     launch_pool(w.c3, w.L3, w.a4, w.L4, 128, s, hk);
-    launch_conv<Tile64x64, 128, 9>(5, KID_CONV4, packed, w.a4, w.b4, w.L4, 1, s, hk);
-    launch_conv<Tile64x64, 128, 9>(6, KID_CONV4, packed, w.b4, w.a4, w.L4, 1, s, hk);
-    launch_conv<Tile64x64, 128, 9>(7, KID_HEADS, packed, w.a4, w.hd, w.L4, 1, s, hk);                      // relu(convPa), relu(convDa)
-    launch_conv<Tile64x64, 256, 1>(8, KID_CONVPB, packed, w.hd, w.lg, w.L4, 0, s, hk);                     // logits
-    launch_conv<Tile64x64, 256, 1>(9, KID_CONVDB, packed, w.hd + (size_t)256 * w.L4.ldt, w.dd, w.L4, 0, s, hk);   // descriptors
+    launch_conv<128, 9>(5, KID_CONV4, packed, w.a4, w.b4, w.L4, 1, s, hk);
+    launch_conv<128, 9>(6, KID_CONV4, packed, w.b4, w.a4, w.L4, 1, s, hk);
+    launch_conv<128, 9>(7, KID_HEADS, packed, w.a4, w.hd, w.L4, 1, s, hk);                                  // relu(convPa), relu(convDa)
+    launch_conv<256, 1>(8, KID_CONVPB, packed, w.hd, w.lg, w.L4, 0, s, hk);                                 // logits
+    launch_conv<256, 1>(9, KID_CONVDB, packed, w.hd + (size_t)256 * w.L4.ldt, w.dd, w.L4, 0, s, hk);       // descriptors
 }
 
 void launch_export_dense(const Workspace& w, float* dense_desc, hipStream_t s) {

@@ -48,12 +48,13 @@ __global__ __launch_bounds__(64) void score_map_kernel(const float* __restrict__
 // Out-of-image taps are -inf exactly as max_pool2d pads.
 // =====================================================================================================
 constexpr int E = NMS_E;
+constexpr int NMS_THREADS = 1024;
 struct NmsSmem {
     float s[E * E], ss[E * E], t[E * E];
     unsigned char m[E * E], sup[E * E], tb[E * E];
 };
 
-__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ score, float* __restrict__ out, int H, int W, int R,
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restrict__ score, float* __restrict__ out, int H, int W, int R,
                                                   int T) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_raw[];
     NmsSmem& S = *reinterpret_cast<NmsSmem*>(nms_raw);
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ scor
         const int y = y0 + i / E, x = x0 + i % E;
         return y >= 0 && y < H && x >= 0 && x < W;
     };
-    for (int i = tid; i < E * E; i += 256) {
+    for (int i = tid; i < E * E; i += NMS_THREADS) {
         const int y = y0 + i / E, x = x0 + i % E;
         S.s[i] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : NINF;
     }
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ scor
     // separable (2R+1)^2 max over the region (taps outside the region are skipped: they only influence
     // positions further than the halo from the tile)
     auto pool_f = [&](const float* in, float* outp) {
-        for (int i = tid; i < E * E; i += 256) {
+        for (int i = tid; i < E * E; i += NMS_THREADS) {
             const int r = i / E, c = i % E;
             float v = NINF;
             for (int d = -R; d <= R; ++d) {
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ scor
             S.t[i] = v;
         }
         __syncthreads();
-        for (int i = tid; i < E * E; i += 256) {
+        for (int i = tid; i < E * E; i += NMS_THREADS) {
             const int r = i / E, c = i % E;
             float v = NINF;
             for (int d = -R; d <= R; ++d) {
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ scor
         __syncthreads();
     };
     auto pool_b = [&](const unsigned char* in, unsigned char* outp) {
-        for (int i = tid; i < E * E; i += 256) {
+        for (int i = tid; i < E * E; i += NMS_THREADS) {
             const int r = i / E, c = i % E;
             unsigned char v = 0;
             for (int d = -R; d <= R; ++d) {
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ scor
             S.tb[i] = v;
         }
         __syncthreads();
-        for (int i = tid; i < E * E; i += 256) {
+        for (int i = tid; i < E * E; i += NMS_THREADS) {
             const int r = i / E, c = i % E;
             unsigned char v = 0;
             for (int d = -R; d <= R; ++d) {
@@ -119,15 +120,15 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ scor
     };
     // max_mask = scores == max_pool(scores)                                        (:56)
     pool_f(S.s, S.ss);
-    for (int i = tid; i < E * E; i += 256) S.m[i] = inside(i) && S.s[i] == S.ss[i];
+    for (int i = tid; i < E * E; i += NMS_THREADS) S.m[i] = inside(i) && S.s[i] == S.ss[i];
     __syncthreads();
     for (int it = 0; it < 2; ++it) {                                                 // (:57-61)
         pool_b(S.m, S.sup);                                                           // supp_mask = max_pool(max_mask) > 0
-        for (int i = tid; i < E * E; i += 256) S.ss[i] = inside(i) ? (S.sup[i] ? 0.f : S.s[i]) : NINF;   // supp_scores
+        for (int i = tid; i < E * E; i += NMS_THREADS) S.ss[i] = inside(i) ? (S.sup[i] ? 0.f : S.s[i]) : NINF;   // supp_scores
         __syncthreads();
         // new_max_mask = supp_scores == max_pool(supp_scores): pooled values go to a register per element
         // (the row pass writes S.t, the column pass is consumed immediately)
-        for (int i = tid; i < E * E; i += 256) {
+        for (int i = tid; i < E * E; i += NMS_THREADS) {
             const int r = i / E, c = i % E;
             float v = NINF;
             for (int d = -R; d <= R; ++d) {
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ scor
             S.t[i] = v;
         }
         __syncthreads();
-        for (int i = tid; i < E * E; i += 256) {
+        for (int i = tid; i < E * E; i += NMS_THREADS) {
             const int r = i / E, c = i % E;
             float v = NINF;
             for (int d = -R; d <= R; ++d) {
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ scor
         __syncthreads();
     }
     float* dst = out + (size_t)im * H * W;
-    for (int i = tid; i < T * T; i += 256) {
+    for (int i = tid; i < T * T; i += NMS_THREADS) {
         const int ty = i / T, tx = i % T;
         const int y = blockIdx.y * T + ty, x = blockIdx.x * T + tx;
         if (y < H && x < W) {
@@ -181,8 +182,8 @@ __global__ __launch_bounds__(64) void rowcount_kernel(const float* __restrict__ 
     if (lane == 0) rowcnt[im * H + y] = cnt;
 }
 
-__global__ __launch_bounds__(1024) void rowscan_kernel(const int* __restrict__ rowcnt, int H, int* __restrict__ rowoff,
-                                                       int* __restrict__ ncand) {
+__global__ __launch_bounds__(1024) void rowscan_kernel(const int* __restrict__ rowcnt, int H, int HW, int* __restrict__ rowoff,
+                                                       int* __restrict__ ncand, int* __restrict__ rank) {
     __shared__ int part[1024];
     const int im = blockIdx.x, tid = threadIdx.x;
     const int per = (H + 1023) / 1024;
@@ -207,7 +208,9 @@ __global__ __launch_bounds__(1024) void rowscan_kernel(const int* __restrict__ r
             run += rowcnt[im * H + y];
         }
     }
-    if (tid == 1023) ncand[im] = part[1023];
+    const int total = part[1023];
+    if (tid == 1023) ncand[im] = total;
+    for (int i = tid; i < total; i += 1024) rank[(size_t)im * HW + i] = 0;      // accumulators of rank_kernel
 }
 
 __global__ __launch_bounds__(64) void compact_kernel(const float* __restrict__ nms, int H, int W, float thr, int border,
@@ -227,73 +230,98 @@ __global__ __launch_bounds__(64) void compact_kernel(const float* __restrict__ n
 
 // =====================================================================================================
 // top_k_keypoints (:73-78) as a rank sort: rank_i = #{j : s_j > s_i or (s_j == s_i and j < i)}; candidate i goes to
-// slot rank_i when rank_i < k.  Deterministic, no cross-workgroup communication.  With n <= k (or k = -1) the
-// row-major list is kept as is.
+// slot rank_i when rank_i < k.  The n x n comparison is tiled over a fixed grid (256 candidates x 1024 rivals per
+// work item); partial ranks are integers, so the atomic accumulation is exact and order-independent.  With n <= k
+// (or k = -1) the row-major list is kept as is.
 // =====================================================================================================
-__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ nms, int HW, const int* __restrict__ ncand,
-                                                     const int* __restrict__ cand, int max_kp, int capacity,
-                                                     int* __restrict__ sel, int32_t* __restrict__ counts) {
-    __shared__ float sj[256];
-    const int im = blockIdx.y, tid = threadIdx.x;
+constexpr int RK_GX = 64, RK_GY = 16, RK_J = 1024;
+
+__global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ nms, int HW, const int* __restrict__ ncand,
+                                                   const int* __restrict__ cand, int max_kp, int* __restrict__ rank) {
+    __shared__ float sj[RK_J];
+    const int im = blockIdx.z, tid = threadIdx.x;
+    const int n = ncand[im];
+    if (max_kp < 0 || n <= max_kp) return;
+    const int* c = cand + (size_t)im * HW;
+    const float* sc = nms + (size_t)im * HW;
+    const int nic = (n + 255) / 256, njc = (n + RK_J - 1) / RK_J;
+    for (int ic = blockIdx.x; ic < nic; ic += RK_GX) {
+        const int i = ic * 256 + tid;
+        const float si = i < n ? sc[c[i]] : 0.f;
+        int r = 0;
+        for (int jc = blockIdx.y; jc < njc; jc += RK_GY) {
+            const int j0 = jc * RK_J;
+            __syncthreads();
+            for (int t = tid; t < RK_J; t += 256) sj[t] = (j0 + t < n) ? sc[c[j0 + t]] : -1.f;
+            __syncthreads();
+            const int lim = min(RK_J, n - j0);
+            for (int j = 0; j < lim; ++j) {
+                const float v = sj[j];
+                r += (v > si) || (v == si && j0 + j < i);
+            }
+        }
+        if (i < n && r) atomicAdd(rank + (size_t)im * HW + i, r);
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_kernel(int HW, const int* __restrict__ ncand, const int* __restrict__ cand,
+                                                      const int* __restrict__ rank, int max_kp, int capacity,
+                                                      int* __restrict__ sel, int32_t* __restrict__ counts) {
+    const int im = blockIdx.y;
     const int n = ncand[im];
     const bool topk = max_kp >= 0 && n > max_kp;
     const int nout = topk ? max_kp : (n < capacity ? n : capacity);
-    if (blockIdx.x == 0 && tid == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         counts[im * 2 + 0] = nout;
         counts[im * 2 + 1] = n;
     }
-    if (blockIdx.x * 256 >= n) return;
-    const int i = blockIdx.x * 256 + tid;
     const int* c = cand + (size_t)im * HW;
+    const int* rk = rank + (size_t)im * HW;
     int* o = sel + (size_t)im * HW;
-    const float* sc = nms + (size_t)im * HW;
-    if (!topk) {
-        if (i < nout) o[i] = c[i];
-        return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int r = topk ? rk[i] : i;
+        if (r < nout) o[r] = c[i];
     }
-    const float si = i < n ? sc[c[i]] : 0.f;
-    int rank = 0;
-    for (int j0 = 0; j0 < n; j0 += 256) {
-        __syncthreads();
-        sj[tid] = (j0 + tid < n) ? sc[c[j0 + tid]] : -1.f;    // scores are > threshold >= ... > -1: never counted
-        __syncthreads();
-        const int lim = min(256, n - j0);
-        for (int j = 0; j < lim; ++j) {
-            const float v = sj[j];
-            rank += (v > si) || (v == si && j0 + j < i);
-        }
-    }
-    if (i < n && rank < max_kp) o[rank] = c[i];
 }
 
 // =====================================================================================================
 // descriptors: 1 / max(||d||, eps) per cell (:185), then per keypoint bilinear sampling of the normalised
-// map and a second normalisation (:81-94).  One workgroup = 64 keypoints x 256 channels.
+// map and a second normalisation (:81-94).
 // =====================================================================================================
 __global__ __launch_bounds__(256) void cellnorm_kernel(DescView dv, int Hc, int Wc, float* __restrict__ invn) {
-    const int cell = blockIdx.x * 256 + threadIdx.x, im = blockIdx.y;
-    if (cell >= Hc * Wc) return;
-    const int cy = cell / Wc, cx = cell - cy * Wc;
-    const float* p = dv.p + (size_t)im * dv.istride + dv.origin + (size_t)cy * dv.rstride + cx;
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int cell = blockIdx.x * 64 + cl, im = blockIdx.y;
     float ss = 0.f;
-    for (int c = 0; c < DD; ++c) {
-        const float v = p[(size_t)c * dv.cstride];
-        ss = fmaf(v, v, ss);
+    if (cell < Hc * Wc) {
+        const int cy = cell / Wc, cx = cell - cy * Wc;
+        const float* p = dv.p + (size_t)im * dv.istride + dv.origin + (size_t)cy * dv.rstride + cx + (size_t)(grp * 64) * dv.cstride;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) {
+            const float v = p[(size_t)c * dv.cstride];
+            ss = fmaf(v, v, ss);
+        }
     }
-    invn[(size_t)im * Hc * Wc + cell] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    part[grp][cl] = ss;
+    __syncthreads();
+    if (grp == 0 && cell < Hc * Wc) {
+        const float tot = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        invn[(size_t)im * Hc * Wc + cell] = 1.f / fmaxf(sqrtf(tot), 1e-12f);
+    }
 }
 
+// one workgroup = 16 keypoints x 256 channels (16 channel groups of 16)
 __global__ __launch_bounds__(256) void sample_kernel(DescView dv, int Hc, int Wc, const float* __restrict__ invn,
                                                      const float* __restrict__ nms, const int* __restrict__ sel,
                                                      const int32_t* __restrict__ counts, int H, int W, int align_corners,
                                                      int capacity, float* __restrict__ keypoints, float* __restrict__ scores,
                                                      float* __restrict__ desc) {
-    __shared__ float part[4][64];
+    __shared__ float part[16][16];
     const int im = blockIdx.y, tid = threadIdx.x;
-    const int kl = tid & 63, grp = tid >> 6;
-    const int slot = blockIdx.x * 64 + kl;
+    const int kl = tid & 15, grp = tid >> 4;
+    const int slot = blockIdx.x * 16 + kl;
     const int nout = counts[im * 2];
-    if (blockIdx.x * 64 >= nout) return;
+    if (blockIdx.x * 16 >= nout) return;
     const bool live = slot < nout;
     int pix = 0;
     if (live) pix = sel[(size_t)im * H * W + slot];
@@ -324,11 +352,11 @@ __global__ __launch_bounds__(256) void sample_kernel(DescView dv, int Hc, int Wc
         off[q] = ok ? yi * dv.rstride + xi : 0;
     }
     const float* base = dv.p + (size_t)im * dv.istride + dv.origin;
-    float v[64];
+    float v[16];
     float ss = 0.f;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        const float* pc = base + (size_t)(grp * 64 + k) * dv.cstride;
+    for (int k = 0; k < 16; ++k) {
+        const float* pc = base + (size_t)(grp * 16 + k) * dv.cstride;
         float a = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) a = fmaf(pc[off[q]], wq[q], a);
@@ -337,12 +365,14 @@ __global__ __launch_bounds__(256) void sample_kernel(DescView dv, int Hc, int Wc
     }
     part[grp][kl] = ss;
     __syncthreads();
-    const float tot = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
+    float tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) tot += part[g][kl];
     const float inv = 1.f / fmaxf(sqrtf(tot), 1e-12f);
     if (!live) return;
     float* d = desc + (size_t)im * DD * capacity + slot;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) d[(size_t)(grp * 64 + k) * capacity] = v[k] * inv;
+    for (int k = 0; k < 16; ++k) d[(size_t)(grp * 16 + k) * capacity] = v[k] * inv;
     if (grp == 0) {
         keypoints[((size_t)im * capacity + slot) * 2 + 0] = (float)px;     // (:180) (h, w) -> (x, y)
         keypoints[((size_t)im * capacity + slot) * 2 + 1] = (float)py;
@@ -375,18 +405,21 @@ void launch_detect(const float* score_map, DescView dv, const Workspace& w, cons
             attr_done[dev] = true;
         }
         const int T = E - 10 * R < 32 ? E - 10 * R : 32;
-        SPP_LAUNCH(hk, KID_NMS, s, nms_kernel, dim3((W + T - 1) / T, (H + T - 1) / T, b), dim3(256), sizeof(NmsSmem), s,
+        SPP_LAUNCH(hk, KID_NMS, s, nms_kernel, dim3((W + T - 1) / T, (H + T - 1) / T, b), dim3(NMS_THREADS), sizeof(NmsSmem), s,
                    score_map, nms, H, W, R, T);
     }
     SPP_LAUNCH(hk, KID_ROWCOUNT, s, rowcount_kernel, dim3(H, b), dim3(64), 0, s, nms, H, W, dp.threshold, dp.remove_borders,
                w.rowcnt);
-    SPP_LAUNCH(hk, KID_SCAN, s, rowscan_kernel, dim3(b), dim3(1024), 0, s, w.rowcnt, H, w.rowoff, w.ncand);
+    SPP_LAUNCH(hk, KID_SCAN, s, rowscan_kernel, dim3(b), dim3(1024), 0, s, w.rowcnt, H, H * W, w.rowoff, w.ncand, w.rank);
     SPP_LAUNCH(hk, KID_COMPACT, s, compact_kernel, dim3(H, b), dim3(64), 0, s, nms, H, W, dp.threshold, dp.remove_borders,
                w.rowoff, w.cand);
-    SPP_LAUNCH(hk, KID_SELECT, s, select_kernel, dim3((H * W + 255) / 256, b), dim3(256), 0, s, nms, H * W, w.ncand, w.cand,
+    if (dp.max_keypoints >= 0)
+        SPP_LAUNCH(hk, KID_RANK, s, rank_kernel, dim3(RK_GX, RK_GY, b), dim3(256), 0, s, nms, H * W, w.ncand, w.cand,
+                   dp.max_keypoints, w.rank);
+    SPP_LAUNCH(hk, KID_SELECT, s, scatter_kernel, dim3(64, b), dim3(256), 0, s, H * W, w.ncand, w.cand, w.rank,
                dp.max_keypoints, dp.capacity, w.sel, counts);
-    SPP_LAUNCH(hk, KID_CELLNORM, s, cellnorm_kernel, dim3((Hc * Wc + 255) / 256, b), dim3(256), 0, s, dv, Hc, Wc, w.invn);
-    SPP_LAUNCH(hk, KID_SAMPLE, s, sample_kernel, dim3((dp.capacity + 63) / 64, b), dim3(256), 0, s, dv, Hc, Wc, w.invn, nms,
+    SPP_LAUNCH(hk, KID_CELLNORM, s, cellnorm_kernel, dim3((Hc * Wc + 63) / 64, b), dim3(256), 0, s, dv, Hc, Wc, w.invn);
+    SPP_LAUNCH(hk, KID_SAMPLE, s, sample_kernel, dim3((dp.capacity + 15) / 16, b), dim3(256), 0, s, dv, Hc, Wc, w.invn, nms,
                w.sel, counts, H, W, dp.align_corners, dp.capacity, keypoints, scores, descriptors);
 }
 

@@ -4,7 +4,7 @@ TEST / BASELINE INFRASTRUCTURE ONLY -- same rules as gatsspg_oracle.py: never im
 Purpose: (1) a second, independent oracle (pinned against the reference goldens in
 tests/test_oracle_golden.py); (2) run on the MI355X through PyTorch-ROCm it is what "the reference on
 this GPU" costs -- every op is a stock ATen / rocBLAS / MIOpen kernel, one launch per op, exactly like the
-reference module (~650-700 device-op launches per forward).  tools/torch_eager_baseline.py
+reference module (~650-700 device-op launches per forward).  bench.py --torch-eager
 times it.  Cites: src/models/GATsSPG_architectures/GATs_SuperGlue.py, GATs.py.
 """
 from __future__ import annotations

@@ -108,3 +108,18 @@ def test_select_ties_and_borders():
     assert yx.tolist() == [[5, 5], [5, 9], [9, 5], [10, 10]]
     yx, _ = so.select_keypoints(s, 0.005, 0, -1)
     assert [2, 8] in yx.tolist()
+
+
+@pytest.mark.parametrize("name", ["tiny_default", "rect_pipeline", "rect_noalign"])
+def test_torch_restatement_matches_reference(name):
+    """oracle/torch_superpoint_oracle.py (the stock-PyTorch baseline of bench.py --extractor --torch-eager)."""
+    import torch
+    from oracle import torch_superpoint_oracle as tso
+    m = META[name]
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_spp_state_dict(m["wseed"]).items()}
+    out = tso.forward(sd, torch.from_numpy(synthetic.make_image(**m["img"])), m["cfg"], align_corners=m["align"])
+    g = load(name)
+    for i in range(m["img"]["b"]):
+        np.testing.assert_array_equal(out["keypoints"][i].numpy(), g[f"keypoints{i}"])
+        np.testing.assert_allclose(out["scores"][i].numpy(), g[f"scores{i}"], atol=1e-6)
+        np.testing.assert_allclose(out["descriptors"][i].numpy(), g[f"descriptors{i}"], atol=1e-6)
