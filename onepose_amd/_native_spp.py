@@ -17,7 +17,7 @@ LAYER_NAMES = ("conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv
                "convPa", "convPb", "convDa", "convDb")
 KERNEL_IDS = {"conv1a": 0, "conv1b": 1, "pool": 2, "conv2": 3, "conv3a": 4, "conv3b": 5, "conv4": 6, "heads": 7,
               "convPb": 8, "convDb": 9, "score_map": 10, "nms": 11, "rowcount": 12, "rowscan": 13, "compact": 14,
-              "select": 15, "cellnorm": 16, "sample": 17, "rank": 18}
+              "select": 15, "cellnorm": 16, "sample": 17, "rank": 18, "scatter": 19}
 
 
 class RawWeights(ctypes.Structure):

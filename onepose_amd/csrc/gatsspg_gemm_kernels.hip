@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
 // tile variants (BN is fixed to MLP0_BN = 64: one InstanceNorm partial per 64-column tile)
 using Mlp0Tile = GemmTile<128, MLP0_BN, 2, 2, false>;
 using Mlp0TileWide = GemmTile<256, MLP0_BN, 4, 1, false>;
+using Mlp0TileW8 = GemmTile<128, MLP0_BN, 4, 2, false>;    // 8 waves, one 32x32 MFMA tile each
 
 // per-workgroup timeline of mlp0_kernel (tools/trace_mlp0.py): 8 x u64 per workgroup
 // [hw_id, xcc_id, t_entry, shader cycles, t_after_mainloop, t_end, rt, ct], 100 MHz wall clock.
@@ -196,7 +197,7 @@ static constexpr unsigned long long* g_trace = nullptr;
 #endif
 
 template <class T, int ABL = 0>
-__global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
+__global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                    const float* __restrict__ Z, const float* __restrict__ MSG,
                                                    float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
                                                    unsigned long long* trace) {
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void mlp0_kernel(const float* __restrict__ W0,
         // contiguous column range, combined by shuffles (fixed order).  One pass, shifted by the row's first column
         // (a pivot within a few std of the mean), so M2 = sum d^2 - (sum d)^2 / n does not cancel even when
         // |mean| >> std; stat_final merges the tiles with Chan's formula.
-        constexpr int LPR = 256 / T::BM;           // lanes per row (2 for BM=128, 1 for BM=256)
+        constexpr int LPR = T::THREADS / T::BM;    // lanes per row (2 for BM=128, 1 for BM=256 on 4 waves)
         constexpr int CPL = T::BN / LPR;           // columns per lane
         const int row = tid / LPR, part = tid % LPR;
         const float pivot = Tl[row * TS];
@@ -588,7 +589,7 @@ static void launch_mlp0_t(const float* W0, const float* b0, const Workspace& w, 
     auto kern = mlp0_kernel<T, ABL>;
     GATSSPG_BIG_LDS_ONCE(kern);
     const int NT = active_tiles(w.L);
-    GATSSPG_LAUNCH(hk, KID_MLP0, s, kern, dim3(xcd_grid(512 / T::BM, NT)), dim3(256),
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, kern, dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
                    shaped_lds(smem_bytes<T>(), 512 / T::BM * NT), s, W0, b0, w.Z, w.MSG, w.U, w.statpart, w.L, g_trace);
 }
 template <class T, int ABL = 0>
@@ -613,6 +614,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else
 #endif
     if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
+    else if (t0 == 2) launch_mlp0_t<Mlp0TileW8>(W0, b0, w, s, hk);
     else launch_mlp0_t<Mlp0Tile>(W0, b0, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
 #ifdef GATSSPG_PROFILING_BUILD

@@ -1,6 +1,6 @@
 // fp32 MFMA GEMM main loop for gfx950 (v_mfma_f32_32x32x2_f32: exact f32 FMA chain at the
-// 157 TFLOP/s matrix rate).  C[BM x BN] += A[BM x K] * B[K x BN], one 256-thread workgroup
-// (4 wave64s arranged WM x WN), K consumed in BK=32 slabs, LDS double-buffered with register
+// 157 TFLOP/s matrix rate).  C[BM x BN] += A[BM x K] * B[K x BN], one workgroup of 4 or 8 wave64s
+// (arranged WM x WN), K consumed in BK=32 slabs, LDS double-buffered with register
 // staging two slabs ahead (two register sets) -- one barrier per slab.
 //
 // Operand layouts
@@ -39,11 +39,12 @@ struct GemmTile {
     static constexpr int B_FLOATS = BK * BN;
     static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
     static constexpr int SMEM_FLOATS = 2 * STAGE_FLOATS;
-    static constexpr int A_VEC = BM * BK / 4 / 256;   // float4 per thread per slab
-    static constexpr int B_VEC = BK * BN / 4 / 256;
-    static_assert(WM * WN == 4, "256-thread workgroup = 4 waves");
+    static constexpr int THREADS = 64 * WM * WN;       // 4 waves (256 threads) or 8 waves (512 threads)
+    static constexpr int A_VEC = BM * BK / 4 / THREADS;   // float4 per thread per slab
+    static constexpr int B_VEC = BK * BN / 4 / THREADS;
+    static_assert(WM * WN == 4 || WM * WN == 8, "workgroup = 4 or 8 waves");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
-    static_assert(A_VEC >= 1 && B_VEC >= 1, "tile too small for 256 threads");
+    static_assert(A_VEC >= 1 && B_VEC >= 1, "tile too small for the workgroup");
 };
 
 // row (within a 32x32 MFMA tile) held by accumulator register r of a lane in half `half`
@@ -107,7 +108,7 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     int a_soff[T::A_VEC], b_soff[T::B_VEC];
 #pragma unroll
     for (int p = 0; p < T::A_VEC; ++p) {
-        const int idx = p * 256 + tid;
+        const int idx = p * T::THREADS + tid;
         if constexpr (T::AKM) {
             const int k = idx / (BM / 4), m = (idx % (BM / 4)) * 4;
             a_goff[p] = 4u * (unsigned)(k * lda + m);
@@ -120,7 +121,7 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     }
 #pragma unroll
     for (int p = 0; p < T::B_VEC; ++p) {
-        const int idx = p * 256 + tid;
+        const int idx = p * T::THREADS + tid;
         const int k = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
         b_goff[p] = 4u * (unsigned)(k * ldb + c);
         x_goff[p] = 4u * (unsigned)k;

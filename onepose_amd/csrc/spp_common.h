@@ -68,7 +68,9 @@ struct Workspace {
     FeatLayout L1, L2, L3, L4;       // full, 1/2, 1/4, 1/8 resolution
     float *a1, *b1, *a2, *b2, *a3, *b3, *c3, *a4, *b4, *hd, *lg, *dd;
     float *score, *nms, *invn;
-    int *rowcnt, *rowoff, *ncand, *cand, *sel, *rank;
+    int *rowcnt, *rowoff, *ncand, *cand, *sel, *rank, *surv;
+    float* cscore;
+    unsigned* skey;
     size_t bytes;
 };
 inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
@@ -103,6 +105,9 @@ inline Workspace carve_workspace(void* base, int b, int H, int W) {
     w.cand = (int*)take(sizeof(int) * px);
     w.sel = (int*)take(sizeof(int) * px);
     w.rank = (int*)take(sizeof(int) * px);
+    w.surv = (int*)take(sizeof(int) * px);
+    w.cscore = (float*)take(sizeof(float) * px);
+    w.skey = (unsigned*)take(sizeof(unsigned) * px);
     w.bytes = off;
     return w;
 }
@@ -111,7 +116,7 @@ inline Workspace carve_workspace(void* base, int b, int H, int W) {
 enum KernelId {
     KID_CONV1A = 0, KID_CONV1B = 1, KID_POOL = 2, KID_CONV2 = 3, KID_CONV3A = 4, KID_CONV3B = 5, KID_CONV4 = 6, KID_HEADS = 7,
     KID_CONVPB = 8, KID_CONVDB = 9, KID_SCORE = 10, KID_NMS = 11, KID_ROWCOUNT = 12, KID_SCAN = 13, KID_COMPACT = 14,
-    KID_SELECT = 15, KID_CELLNORM = 16, KID_SAMPLE = 17, KID_RANK = 18, KID_COUNT = 19
+    KID_SELECT = 15, KID_CELLNORM = 16, KID_SAMPLE = 17, KID_RANK = 18, KID_SCATTER = 19, KID_COUNT = 20
 };
 struct ProfileHook {
     int kernel_id, occurrence;

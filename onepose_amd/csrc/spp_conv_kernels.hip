@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ i
 // X [CIN][ldt] -> Y [cout][ldt]; pad positions of Y are written as zeros.
 // =====================================================================================================
 template <class T, int CIN, int TAPS>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const float* __restrict__ Wt, const float* __restrict__ bias,
+__global__ __launch_bounds__(T::THREADS) void conv_gemm_kernel(const float* __restrict__ Wt, const float* __restrict__ bias,
                                                         const float* __restrict__ X, float* __restrict__ Y, FeatLayout L,
                                                         int cout, int relu) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -176,6 +176,8 @@ void launch_pack_weights(const void* raw_host, float* packed, hipStream_t s) {
 using Tile64x128 = GemmTile<64, 128, 1, 4, false, true>;
 using Tile64x64 = GemmTile<64, 64, 2, 2, false, true>;
 using Tile128x64 = GemmTile<128, 64, 2, 2, false, true>;
+using Tile64x128w8 = GemmTile<64, 128, 2, 4, false, true>;    // 8 waves, one 32x32 MFMA tile each
+using Tile128x64w8 = GemmTile<128, 64, 4, 2, false, true>;
 
 template <class T, int CIN, int TAPS>
 static void launch_conv_t(int gi, int kid, const float* packed, const float* X, float* Y, const FeatLayout& L, int relu,
@@ -183,11 +185,12 @@ static void launch_conv_t(int gi, int kid, const float* packed, const float* X, 
     auto kern = conv_gemm_kernel<T, CIN, TAPS>;
     const int cout = kConv[gi].cout;
     const int MT = (cout + T::BM - 1) / T::BM, NT = L.ldt / T::BN;
-    SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(MT, NT)), dim3(256), smem_bytes<T>(), s, packed + conv_w_off(gi),
+    SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(MT, NT)), dim3(T::THREADS), smem_bytes<T>(), s, packed + conv_w_off(gi),
                packed + conv_b_off(gi), X, Y, L, cout, relu);
 }
 
-// Tile shape per GEMM convolution: 0 = 64x128, 1 = 64x64, 2 = 128x64 (rows x columns).  SPP_TILES="a,b,..." (ten
+// Tile shape per GEMM convolution: 0 = 64x128, 1 = 64x64, 2 = 128x64 (rows x columns), 3 = 64x128 on 8 waves,
+// 4 = 128x64 on 8 waves.  SPP_TILES="a,b,..." (ten
 // comma-separated ids, forward order conv1b..convDb) overrides the defaults for tuning; every choice is equally correct.
 static const int* conv_tiles() {
     static int tiles[NGEMM] = {0, 0, 0, 1, 1, 1, 1, 1, 1, 1};
@@ -197,10 +200,10 @@ static const int* conv_tiles() {
         if (const char* e = getenv("SPP_TILES")) {
             int i = 0;
             for (const char* p = e; *p && i < NGEMM; ++p)
-                if (*p >= '0' && *p <= '2') tiles[i++] = *p - '0';
+                if (*p >= '0' && *p <= '4') tiles[i++] = *p - '0';
         }
         for (int i = 0; i < NGEMM; ++i)
-            if (tiles[i] == 2 && kConv[i].rows % 128) tiles[i] = 1;
+            if ((tiles[i] == 2 || tiles[i] == 4) && kConv[i].rows % 128) tiles[i] = 1;
     }
     return tiles;
 }
@@ -211,6 +214,8 @@ static void launch_conv(int gi, int kid, const float* packed, const float* X, fl
     switch (conv_tiles()[gi]) {
         case 0: launch_conv_t<Tile64x128, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
         case 2: launch_conv_t<Tile128x64, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+        case 3: launch_conv_t<Tile64x128w8, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+        case 4: launch_conv_t<Tile128x64w8, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
         default: launch_conv_t<Tile64x64, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
     }
 }

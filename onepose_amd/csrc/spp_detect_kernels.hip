@@ -182,8 +182,8 @@ __global__ __launch_bounds__(64) void rowcount_kernel(const float* __restrict__ 
     if (lane == 0) rowcnt[im * H + y] = cnt;
 }
 
-__global__ __launch_bounds__(1024) void rowscan_kernel(const int* __restrict__ rowcnt, int H, int HW, int* __restrict__ rowoff,
-                                                       int* __restrict__ ncand, int* __restrict__ rank) {
+__global__ __launch_bounds__(1024) void rowscan_kernel(const int* __restrict__ rowcnt, int H, int* __restrict__ rowoff,
+                                                       int* __restrict__ ncand) {
     __shared__ int part[1024];
     const int im = blockIdx.x, tid = threadIdx.x;
     const int per = (H + 1023) / 1024;
@@ -208,65 +208,174 @@ __global__ __launch_bounds__(1024) void rowscan_kernel(const int* __restrict__ r
             run += rowcnt[im * H + y];
         }
     }
-    const int total = part[1023];
-    if (tid == 1023) ncand[im] = total;
-    for (int i = tid; i < total; i += 1024) rank[(size_t)im * HW + i] = 0;      // accumulators of rank_kernel
+    if (tid == 1023) ncand[im] = part[1023];
 }
 
 __global__ __launch_bounds__(64) void compact_kernel(const float* __restrict__ nms, int H, int W, float thr, int border,
-                                                     const int* __restrict__ rowoff, int* __restrict__ cand) {
+                                                     const int* __restrict__ rowoff, int* __restrict__ cand,
+                                                     float* __restrict__ cscore) {
     const int y = blockIdx.x, im = blockIdx.y, lane = threadIdx.x;
     const float* row = nms + ((size_t)im * H + y) * W;
     int base = rowoff[im * H + y];
     int* dst = cand + (size_t)im * H * W;
+    float* sdst = cscore + (size_t)im * H * W;
     for (int x0 = 0; x0 < W; x0 += 64) {
         const int x = x0 + lane;
-        const bool p = x < W && is_keypoint(row[x < W ? x : 0], y, x, H, W, thr, border);
+        const float v = row[x < W ? x : 0];
+        const bool p = x < W && is_keypoint(v, y, x, H, W, thr, border);
         const unsigned long long mask = __ballot(p);
-        if (p) dst[base + __popcll(mask & ((1ull << lane) - 1ull))] = y * W + x;
+        if (p) {
+            const int o = base + __popcll(mask & ((1ull << lane) - 1ull));
+            dst[o] = y * W + x;
+            sdst[o] = v;                       // dense copy of the candidate scores for the top-k passes
+        }
         base += __popcll(mask);
     }
 }
 
 // =====================================================================================================
-// top_k_keypoints (:73-78) as a rank sort: rank_i = #{j : s_j > s_i or (s_j == s_i and j < i)}; candidate i goes to
-// slot rank_i when rank_i < k.  The n x n comparison is tiled over a fixed grid (256 candidates x 1024 rivals per
-// work item); partial ranks are integers, so the atomic accumulation is exact and order-independent.  With n <= k
-// (or k = -1) the row-major list is kept as is.
+// top_k_keypoints (:73-78), engaged when more than k candidates survive:
+//   1. select_kernel (one workgroup per image): radix select on the fp32 bit patterns (scores are >= 0, so the
+//      unsigned order of the bits is the order of the values) finds the k-th largest score T in three histogram
+//      passes (12 + 12 + 8 bits); the k survivors -- score > T, plus the lowest-index candidates among those equal to
+//      T -- are compacted in candidate (row-major) order;
+//   2. rank_kernel: rank_i = #{j : s_j > s_i or (s_j == s_i and j < i)} among the k survivors, tiled over a fixed grid;
+//      partial ranks are integers, so the atomic accumulation is exact and order-independent;
+//   3. scatter_kernel: survivor i goes to output slot rank_i (descending score, ties by lower pixel index).
+// With n <= k (or k = -1) the row-major list is kept as is.
 // =====================================================================================================
-constexpr int RK_GX = 64, RK_GY = 16, RK_J = 1024;
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total) {
+    // exclusive prefix sum of one int per thread over a 1024-thread workgroup (thread order)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int t = wsum[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    total = tot;
+    return base + inc - v;
+}
 
-__global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ nms, int HW, const int* __restrict__ ncand,
-                                                   const int* __restrict__ cand, int max_kp, int* __restrict__ rank) {
-    __shared__ float sj[RK_J];
-    const int im = blockIdx.z, tid = threadIdx.x;
+__global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ cscore, int HW, const int* __restrict__ ncand,
+                                                      const int* __restrict__ cand, int max_kp, int* __restrict__ surv,
+                                                      unsigned* __restrict__ skey, int* __restrict__ rank) {
+    __shared__ int hist[4096];
+    __shared__ int wsum[16];
+    __shared__ int sh_bin, sh_need;
+    const int im = blockIdx.x, tid = threadIdx.x;
     const int n = ncand[im];
     if (max_kp < 0 || n <= max_kp) return;
     const int* c = cand + (size_t)im * HW;
-    const float* sc = nms + (size_t)im * HW;
+    const unsigned* key = reinterpret_cast<const unsigned*>(cscore + (size_t)im * HW);   // key[i] = bits of candidate i's score
+    // one radix digit: histogram of digit (k >> shift) & (bins-1) over keys whose higher bits equal `prefix`;
+    // then the largest digit d with #{digit >= d} >= need.  Returns d, updates need -= #{digit > d}.
+    auto digit = [&](unsigned prefix, int pshift, int shift, int bins, int need) {
+        for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned k = key[i];
+            if (pshift >= 32 || (k >> pshift) == prefix) atomicAdd(&hist[(k >> shift) & (bins - 1)], 1);
+        }
+        __syncthreads();
+        // suffix counts: thread t owns bins [4t, 4t+4) (descending scan = exclusive prefix over reversed thread order)
+        const int rt = 1023 - tid;                   // reversed owner: thread 0 handles the highest bins
+        int loc[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int bin = rt * 4 + (3 - q);        // descending bin order within the thread
+            loc[q] = bin < bins ? hist[bin] : 0;
+            sum += loc[q];
+        }
+        int total;
+        int above = block_excl_scan(sum, wsum, total);   // keys in bins above this thread's range
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int bin = rt * 4 + (3 - q);
+            if (bin < bins && above < need && above + loc[q] >= need) {
+                sh_bin = bin;
+                sh_need = need - above;
+            }
+            above += loc[q];
+        }
+        __syncthreads();
+    };
+    digit(0u, 32, 20, 4096, max_kp);
+    const unsigned b1 = (unsigned)sh_bin;
+    const int need1 = sh_need;
+    __syncthreads();
+    digit(b1, 20, 8, 4096, need1);
+    const unsigned b2 = (unsigned)sh_bin;
+    const int need2 = sh_need;
+    __syncthreads();
+    digit((b1 << 12) | b2, 8, 0, 256, need2);
+    const unsigned T = (b1 << 20) | (b2 << 8) | (unsigned)sh_bin;
+    const int quota = sh_need;                       // candidates equal to T that make the cut (lowest index first)
+    __syncthreads();
+    // ordered compaction of the k survivors
+    int* sv = surv + (size_t)im * HW;
+    unsigned* sk = skey + (size_t)im * HW;
+    int* rk = rank + (size_t)im * HW;
+    int ties_before = 0, out_before = 0;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const unsigned k = i < n ? key[i] : 0u;
+        const int tie = i < n && k == T;
+        int tot_t, tot_o;
+        const int tpos = ties_before + block_excl_scan(tie, wsum, tot_t);
+        const int keep = i < n && (k > T || (tie && tpos < quota));
+        const int opos = out_before + block_excl_scan(keep, wsum, tot_o);
+        if (keep) {
+            sv[opos] = c[i];
+            sk[opos] = k;
+        }
+        ties_before += tot_t;
+        out_before += tot_o;
+    }
+    for (int i = tid; i < max_kp; i += 1024) rk[i] = 0;      // accumulators of rank_kernel
+}
+
+constexpr int RK_GX = 64, RK_GY = 16, RK_J = 256;
+
+__global__ __launch_bounds__(256) void rank_kernel(const unsigned* __restrict__ skey, int HW, const int* __restrict__ ncand,
+                                                   int max_kp, int* __restrict__ rank) {
+    __shared__ unsigned long long sj[RK_J];
+    const int im = blockIdx.z, tid = threadIdx.x;
+    if (max_kp < 0 || ncand[im] <= max_kp) return;
+    const int n = max_kp;                                     // the survivors of select_kernel
+    const unsigned* key = skey + (size_t)im * HW;
+    // composite key: (score bits, ~position) -> "greater" = higher score, or equal score and lower position
+    auto ckey = [&](int i) { return ((unsigned long long)key[i] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i); };
     const int nic = (n + 255) / 256, njc = (n + RK_J - 1) / RK_J;
     for (int ic = blockIdx.x; ic < nic; ic += RK_GX) {
         const int i = ic * 256 + tid;
-        const float si = i < n ? sc[c[i]] : 0.f;
+        const unsigned long long ki = i < n ? ckey(i) : ~0ull;
         int r = 0;
         for (int jc = blockIdx.y; jc < njc; jc += RK_GY) {
             const int j0 = jc * RK_J;
             __syncthreads();
-            for (int t = tid; t < RK_J; t += 256) sj[t] = (j0 + t < n) ? sc[c[j0 + t]] : -1.f;
+            for (int t = tid; t < RK_J; t += 256) sj[t] = (j0 + t < n) ? ckey(j0 + t) : 0ull;
             __syncthreads();
-            const int lim = min(RK_J, n - j0);
-            for (int j = 0; j < lim; ++j) {
-                const float v = sj[j];
-                r += (v > si) || (v == si && j0 + j < i);
-            }
+#pragma unroll 8
+            for (int j = 0; j < RK_J; ++j) r += sj[j] > ki;
         }
         if (i < n && r) atomicAdd(rank + (size_t)im * HW + i, r);
     }
 }
 
 __global__ __launch_bounds__(256) void scatter_kernel(int HW, const int* __restrict__ ncand, const int* __restrict__ cand,
-                                                      const int* __restrict__ rank, int max_kp, int capacity,
-                                                      int* __restrict__ sel, int32_t* __restrict__ counts) {
+                                                      const int* __restrict__ surv, const int* __restrict__ rank, int max_kp,
+                                                      int capacity, int* __restrict__ sel, int32_t* __restrict__ counts) {
     const int im = blockIdx.y;
     const int n = ncand[im];
     const bool topk = max_kp >= 0 && n > max_kp;
@@ -275,13 +384,10 @@ __global__ __launch_bounds__(256) void scatter_kernel(int HW, const int* __restr
         counts[im * 2 + 0] = nout;
         counts[im * 2 + 1] = n;
     }
-    const int* c = cand + (size_t)im * HW;
+    const int* src = (topk ? surv : cand) + (size_t)im * HW;
     const int* rk = rank + (size_t)im * HW;
     int* o = sel + (size_t)im * HW;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int r = topk ? rk[i] : i;
-        if (r < nout) o[r] = c[i];
-    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nout; i += gridDim.x * 256) o[topk ? rk[i] : i] = src[i];
 }
 
 // =====================================================================================================
@@ -410,13 +516,16 @@ void launch_detect(const float* score_map, DescView dv, const Workspace& w, cons
     }
     SPP_LAUNCH(hk, KID_ROWCOUNT, s, rowcount_kernel, dim3(H, b), dim3(64), 0, s, nms, H, W, dp.threshold, dp.remove_borders,
                w.rowcnt);
-    SPP_LAUNCH(hk, KID_SCAN, s, rowscan_kernel, dim3(b), dim3(1024), 0, s, w.rowcnt, H, H * W, w.rowoff, w.ncand, w.rank);
+    SPP_LAUNCH(hk, KID_SCAN, s, rowscan_kernel, dim3(b), dim3(1024), 0, s, w.rowcnt, H, w.rowoff, w.ncand);
     SPP_LAUNCH(hk, KID_COMPACT, s, compact_kernel, dim3(H, b), dim3(64), 0, s, nms, H, W, dp.threshold, dp.remove_borders,
-               w.rowoff, w.cand);
-    if (dp.max_keypoints >= 0)
-        SPP_LAUNCH(hk, KID_RANK, s, rank_kernel, dim3(RK_GX, RK_GY, b), dim3(256), 0, s, nms, H * W, w.ncand, w.cand,
+               w.rowoff, w.cand, w.cscore);
+    if (dp.max_keypoints >= 0) {
+        SPP_LAUNCH(hk, KID_SELECT, s, select_kernel, dim3(b), dim3(1024), 0, s, w.cscore, H * W, w.ncand, w.cand,
+                   dp.max_keypoints, w.surv, w.skey, w.rank);
+        SPP_LAUNCH(hk, KID_RANK, s, rank_kernel, dim3(RK_GX, RK_GY, b), dim3(256), 0, s, w.skey, H * W, w.ncand,
                    dp.max_keypoints, w.rank);
-    SPP_LAUNCH(hk, KID_SELECT, s, scatter_kernel, dim3(64, b), dim3(256), 0, s, H * W, w.ncand, w.cand, w.rank,
+    }
+    SPP_LAUNCH(hk, KID_SCATTER, s, scatter_kernel, dim3(16, b), dim3(256), 0, s, H * W, w.ncand, w.cand, w.surv, w.rank,
                dp.max_keypoints, dp.capacity, w.sel, counts);
     SPP_LAUNCH(hk, KID_CELLNORM, s, cellnorm_kernel, dim3((Hc * Wc + 63) / 64, b), dim3(256), 0, s, dv, Hc, Wc, w.invn);
     SPP_LAUNCH(hk, KID_SAMPLE, s, sample_kernel, dim3((dp.capacity + 15) / 16, b), dim3(256), 0, s, dv, Hc, Wc, w.invn, nms,
