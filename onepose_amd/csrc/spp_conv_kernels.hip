@@ -73,8 +73,15 @@ __global__ __launch_bounds__(T::THREADS) void conv_gemm_kernel(const float* __re
     static_assert(KT % 2 == 0, "the main loop consumes slabs in pairs");
     const int MT = (cout + T::BM - 1) / T::BM;
     const int NT = L.ldt / T::BN;
-    int rt, ct;
-    if (!gatsspg::xcd_tile_map(MT, NT, rt, ct)) return;
+    // XCD-aware tile map (workgroup g runs on XCD g % 8): every XCD owns one contiguous band of column tiles, i.e. a
+    // band of image rows, and walks it top to bottom with the row tiles of a column tile back to back.  The dy = +-1 taps
+    // of a tile read the rows of the tiles one image row above / below; with bands those are in the same XCD's L2
+    // (a round-robin map puts them on other XCDs and every input row is fetched into three L2s).
+    const int per = (NT + 7) / 8;
+    const int slot = blockIdx.x >> 3;
+    const int rt = slot % MT;
+    const int ct = (blockIdx.x & 7) * per + slot / MT;
+    if (slot / MT >= per || ct >= NT) return;
     const int c0 = ct * T::BN, ldt = L.ldt, Wp = L.Wp;
     const float* A = Wt + (size_t)rt * T::BM * (TAPS * CIN);
     f32x16 acc[T::TM][T::TN];

@@ -249,3 +249,47 @@ def test_bad_arguments_raise():
     mod.config["nms_radius"] = 9
     with pytest.raises(NativeError, match="nms_radius"):
         mod(torch.zeros(1, 1, 64, 64).cuda())
+
+
+@pytest.mark.parametrize("b,h,w", [(1, 8, 8), (2, 8, 24), (1, 16, 512), (3, 40, 72)])
+def test_small_and_skinny_images_vs_oracle(b, h, w):
+    """Smallest legal image (one 8x8 cell), single-cell rows, very skinny planes, odd batch."""
+    cfg = {"nms_radius": 2, "remove_borders": 0, "keypoint_threshold": 0.001, "max_keypoints": -1}
+    mod, sd = make_module(b + h, cfg)
+    img = synthetic.make_image(b, h, w, 7 * h + w)
+    out = mod(torch.from_numpy(img).cuda())
+    ref = so.forward(sd, img, cfg)
+    for i in range(b):
+        kp, rk = out["keypoints"][i].cpu().numpy(), ref["keypoints"][i]
+        diff = set(map(tuple, kp.tolist())) ^ set(map(tuple, rk.tolist()))
+        assert len(diff) <= 1, diff                        # a score within fp32 noise of the threshold may flip
+        if not diff:
+            np.testing.assert_array_equal(kp, rk)
+            np.testing.assert_allclose(out["scores"][i].cpu().numpy(), ref["scores"][i], atol=ATOL_SCORE)
+            np.testing.assert_allclose(out["descriptors"][i].cpu().numpy(), ref["descriptors"][i], atol=ATOL_DESC)
+
+
+def test_forward_is_capturable_in_a_hip_graph():
+    """spp_forward never allocates or synchronises: one image's whole extractor replays from a hipGraph."""
+    cfg = {"nms_radius": 3, "max_keypoints": 300}
+    mod, _ = make_module(2, cfg)
+    img = torch.from_numpy(synthetic.make_image(1, 128, 128, 3)).cuda()
+    eager = mod.forward_device(img)                       # also packs the weights / sizes the workspace outside the capture
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    static_img = img.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        mod.forward_device(static_img)                    # warm-up on the capture stream
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=stream):
+            captured = mod.forward_device(static_img)
+    static_img.copy_(torch.from_numpy(synthetic.make_image(1, 128, 128, 4)).cuda())
+    g.replay()
+    torch.cuda.synchronize()
+    fresh = mod.forward_device(static_img.clone())
+    torch.cuda.synchronize()
+    n = int(fresh[3][0, 0])
+    assert n == int(captured[3][0, 0]) == 300
+    assert torch.equal(captured[0][0, :n], fresh[0][0, :n]) and torch.equal(captured[2][0, :, :n], fresh[2][0, :, :n])
+    assert not torch.equal(captured[0][0, :n], eager[0][0, :n])      # the replay really saw the new image

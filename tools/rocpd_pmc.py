@@ -2,7 +2,10 @@
 """Per-kernel PMC summary from a rocprofv3 rocpd SQLite file (counter values summed over all
 instances/dimensions of a dispatch, averaged over the dispatches of each kernel).
 
-    python tools/rocpd_pmc.py gpurun_out/pmc1/pmc_results.db
+    python tools/rocpd_pmc.py gpurun_out/pmc1/pmc_results.db [--by-grid]
+
+--by-grid keeps launches of one kernel with different grid sizes apart (the SuperPoint convolutions are one template
+launched on four resolutions) and prints the full template arguments.
 """
 import collections
 import sqlite3
@@ -18,8 +21,10 @@ def main():
     name_col = "kernel_name" if "kernel_name" in scols else "display_name"
     names = dict(db.execute(f"select id, name from {ip}"))
     disp = {}
-    for ev, kname, st, en in db.execute(f"select d.event_id, s.{name_col}, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id"):
-        disp[ev] = (kname.split("(")[0].replace("gatsspg::", "")[:48], en - st)
+    by_grid = "--by-grid" in sys.argv
+    for ev, kname, st, en, gx in db.execute(f"select d.event_id, s.{name_col}, d.start, d.end, d.grid_size_x from {kd} d join {ks} s on d.kernel_id=s.id"):
+        base = kname.split("(")[0].replace("gatsspg::", "")
+        disp[ev] = ((base[:96] + f" grid={gx}") if by_grid else base[:48], en - st)
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
     dur = collections.defaultdict(float)
@@ -37,7 +42,7 @@ def main():
     print("# kernel calls avg_us " + " ".join(ctrs))
     for k in sorted(per, key=lambda k: -dur[k]):
         n = cnt[k]
-        print(f"{k:50s} {n:5d} {dur[k] / n / 1e3:9.2f} " + " ".join(f"{per[k][c] / n:14.1f}" for c in ctrs))
+        print(f"{k:{110 if by_grid else 50}s} {n:5d} {dur[k] / n / 1e3:9.2f} " + " ".join(f"{per[k][c] / n:14.1f}" for c in ctrs))
 
 
 if __name__ == "__main__":
