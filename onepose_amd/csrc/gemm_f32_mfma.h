@@ -61,6 +61,11 @@ __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * 
 struct NoXform {
     __device__ __forceinline__ void operator()(vf4&, float2) const {}
 };
+// tile column (multiple of 4) -> element offset from the B slab pointer; identity for a contiguous column tile.
+// The SuperPoint conv+pool kernels use a 2-row x 64-column image patch as their 128 "columns".
+struct IdentityCol {
+    __device__ __forceinline__ int operator()(int c) const { return c; }
+};
 __device__ __forceinline__ vf4 ldg4_off(const float* base, unsigned byte_off) {
     return *reinterpret_cast<const vf4*>(reinterpret_cast<const char*>(base) + byte_off);
 }
@@ -92,9 +97,11 @@ __device__ __forceinline__ void sched_interleave_vmem() {
 // ABLATE (profiling only, wrong results): 1 = no global loads in the steady-state loop,
 //   2 = no global loads and no LDS writes, 3 = steady-state loop cut to one step pair,
 //   6 = every load of a wave hits the same 1 KiB (always L1-hot)
-template <class T, class ASlab, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, int ABLATE = 0>
+template <class T, class ASlab, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, int ABLATE = 0,
+          class BCol = IdentityCol>
 __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
-                                                 BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform) {
+                                                 BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform,
+                                                 BCol bcol = BCol()) {
     constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN;
     constexpr bool FINE_INTERLEAVE = false;
     const int tid = threadIdx.x;
@@ -123,7 +130,7 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     for (int p = 0; p < T::B_VEC; ++p) {
         const int idx = p * T::THREADS + tid;
         const int k = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
-        b_goff[p] = 4u * (unsigned)(k * ldb + c);
+        b_goff[p] = 4u * (unsigned)(k * ldb + bcol(c));
         x_goff[p] = 4u * (unsigned)k;
         b_soff[p] = T::A_FLOATS + k * BN + c;
     }
@@ -285,12 +292,12 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
 }
 
 // convenience wrapper without per-row aux / transform
-template <class T, class ASlab, class BSlab, int ABLATE = 0>
+template <class T, class ASlab, class BSlab, int ABLATE = 0, class BCol = IdentityCol>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
-                                              BSlab b_slab, int ldb) {
+                                              BSlab b_slab, int ldb, BCol bcol = BCol()) {
     auto nox = [](int) { return static_cast<const float*>(nullptr); };
-    gemm_mainloop_ex<T, ASlab, BSlab, decltype(nox), decltype(nox), NoXform, false, ABLATE>(acc, smem, KT, a_slab, lda, b_slab,
-                                                                                          ldb, nox, nox, NoXform());
+    gemm_mainloop_ex<T, ASlab, BSlab, decltype(nox), decltype(nox), NoXform, false, ABLATE, BCol>(
+        acc, smem, KT, a_slab, lda, b_slab, ldb, nox, nox, NoXform(), bcol);
 }
 
 template <int TM, int TN>

@@ -25,8 +25,44 @@ constexpr size_t smem_bytes() { return sizeof(float) * T::SMEM_FLOATS; }
 // =====================================================================================================
 // conv1a + ReLU (:142): one thread per padded position, all 64 output channels
 // =====================================================================================================
+// zero the one-pixel pad ring of every channel plane of P (the fused conv+pool epilogues write pixels only)
+__device__ void zero_pad_ring(float* __restrict__ P, const FeatLayout& L, int C, int worker, int nworkers) {
+    const int ring = 2 * L.Wp + 2 * L.H;                 // top row, bottom row, left + right columns
+    const long long total = (long long)C * L.b * ring;
+    for (long long i = worker; i < total; i += nworkers) {
+        const int r = (int)(i % ring);
+        const long long ci = i / ring;
+        const int im = (int)(ci % L.b), c = (int)(ci / L.b);
+        int q;
+        if (r < L.Wp) q = r;                                                   // y = 0
+        else if (r < 2 * L.Wp) q = (L.H + 1) * L.Wp + (r - L.Wp);              // y = H + 1
+        else {
+            const int k = r - 2 * L.Wp, y = 1 + (k >> 1);
+            q = y * L.Wp + ((k & 1) ? L.Wp - 1 : 0);
+        }
+        P[(size_t)c * L.ldt + (size_t)im * L.ld + q] = 0.f;
+    }
+}
+
+struct PadPlanes {
+    float *p2, *p3, *p4;
+    FeatLayout L2, L3, L4;
+    int nblocks;      // workgroups of conv1a_kernel (after the image ones) that do this
+};
+
 __global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ img, const float* __restrict__ w9,
-                                                     const float* __restrict__ bias, float* __restrict__ Y, FeatLayout L) {
+                                                     const float* __restrict__ bias, float* __restrict__ Y, FeatLayout L,
+                                                     PadPlanes pp) {
+    const int img_blocks = (L.ld + 255) / 256;
+    if ((int)blockIdx.x >= img_blocks) {
+        if (blockIdx.y == 0) {
+            const int worker = (blockIdx.x - img_blocks) * 256 + threadIdx.x, nworkers = pp.nblocks * 256;
+            zero_pad_ring(pp.p2, pp.L2, 64, worker, nworkers);
+            zero_pad_ring(pp.p3, pp.L3, 64, worker, nworkers);
+            zero_pad_ring(pp.p4, pp.L4, 128, worker, nworkers);
+        }
+        return;
+    }
     __shared__ float sw[64 * 9 + 64];
     for (int i = threadIdx.x; i < 64 * 9; i += 256) sw[i] = w9[i];
     if (threadIdx.x < 64) sw[576 + threadIdx.x] = bias[threadIdx.x];
@@ -113,6 +149,74 @@ __global__ __launch_bounds__(T::THREADS) void conv_gemm_kernel(const float* __re
                     Y[(size_t)row * ldt + col] = ok ? v : 0.f;
                 }
             }
+    }
+}
+
+// =====================================================================================================
+// 3x3 convolution + bias + ReLU + MaxPool2d(2, 2) (:143-151: conv1b, conv2b, conv3b feed only the pool).
+// The 128 GEMM "columns" of a workgroup are a 2-row x 64-column image patch (the column map of the main loop sends
+// column c to row c / 64, x = c % 64), so the 2x2 maxima are workgroup-local: the full-resolution activation is never
+// written (conv1b: 67.7 MB less HBM traffic, one launch less per resolution).  Y2 is the half-resolution padded plane;
+// only its pixels are written (its pad ring is zeroed once per forward by conv1a_kernel's extra workgroups).
+// =====================================================================================================
+struct PatchCol {
+    int Wp;
+    __device__ __forceinline__ int operator()(int c) const { return (c & 63) + (c >> 6) * Wp; }
+};
+
+template <class T, int CIN>
+__global__ __launch_bounds__(T::THREADS) void conv_pool_kernel(const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                               const float* __restrict__ X, float* __restrict__ Y2, FeatLayout L,
+                                                               FeatLayout L2, int cout) {
+    static_assert(T::BN == 128 && T::BM == 64, "2 x 64 pixel patch, 64 output channels per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CPS = CIN / BK, KT = 9 * CPS;
+    static_assert(KT % 2 == 0, "the main loop consumes slabs in pairs");
+    const int SEG = (L.W + 63) / 64, HP = L.H / 2;
+    const int MT = cout / T::BM, NT = L.b * HP * SEG;
+    const int per = (NT + 7) / 8;                      // XCD bands of consecutive patches (see conv_gemm_kernel)
+    const int slot = blockIdx.x >> 3;
+    const int rt = slot % MT;
+    const int t = (blockIdx.x & 7) * per + slot / MT;
+    if (slot / MT >= per || t >= NT) return;
+    const int im = t / (HP * SEG), r = t - im * (HP * SEG);
+    const int yp = r / SEG, sx = r - yp * SEG;         // pooled row, 64-pixel segment
+    const int ldt = L.ldt, Wp = L.Wp;
+    const int c0 = im * L.ld + (1 + 2 * yp) * Wp + 1 + 64 * sx;
+    const float* A = Wt + (size_t)rt * T::BM * (9 * CIN);
+    f32x16 acc[T::TM][T::TN];
+    gatsspg::zero_acc(acc);
+    auto al = [&](int kt) { return A + kt * BK; };
+    auto bl = [&](int kt) {
+        const int tap = kt / CPS, cc = kt - tap * CPS;
+        return X + ((ptrdiff_t)cc * BK * ldt + c0 + (tap / 3 - 1) * Wp + (tap % 3 - 1));
+    };
+    gatsspg::gemm_mainloop<T, decltype(al), decltype(bl), 0, PatchCol>(acc, smem, KT, al, 9 * CIN, bl, ldt, PatchCol{Wp});
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    constexpr int TS = T::BN + 4;                      // [64][132] staging tile in the (now free) operand buffers
+    static_assert(T::BM * TS <= T::SMEM_FLOATS, "staging tile must fit the operand buffers");
+    __syncthreads();
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = (wm * T::TM + tm) * 32 + mfma_row(rr, half);
+                const int col = (wn * T::TN + tn) * 32 + l31;
+                smem[row * TS + col] = fmaxf(acc[tm][tn][rr] + bias[rt * T::BM + row], 0.f);
+            }
+    __syncthreads();
+    const int W2 = L.W / 2;
+    float* dst = Y2 + (size_t)im * L2.ld + (size_t)(yp + 1) * L2.Wp + 1 + 32 * sx;
+    for (int p = tid; p < T::BM * 32; p += T::THREADS) {
+        const int ch = p >> 5, px = p & 31;
+        if (32 * sx + px < W2) {
+            const float* s0 = smem + ch * TS + 2 * px;
+            dst[(size_t)(rt * T::BM + ch) * L2.ldt + px] = fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[64], s0[65]));
+        }
     }
 }
 
@@ -232,17 +336,33 @@ static void launch_pool(const float* X, const FeatLayout& Li, float* Y, const Fe
     SPP_LAUNCH(hk, KID_POOL, s, pool_kernel, dim3((Lo.ld + 255) / 256, C, Lo.b), dim3(256), 0, s, X, Li, Y, Lo);
 }
 
+// conv + ReLU + 2x2 pool in one launch (SPP_FUSE_POOL=0 falls back to the two-kernel form for A/B timing)
+template <int CIN>
+static void launch_conv_pool(int gi, int kid, const float* packed, const float* X, float* tmp, float* Y2, const FeatLayout& L,
+                             const FeatLayout& L2, hipStream_t s, ProfileHook* hk) {
+    static const bool fuse = !(getenv("SPP_FUSE_POOL") && atoi(getenv("SPP_FUSE_POOL")) == 0);
+    const int cout = kConv[gi].cout;
+    if (!fuse) {
+        launch_conv<CIN, 9>(gi, kid, packed, X, tmp, L, 1, s, hk);
+        launch_pool(tmp, L, Y2, L2, cout, s, hk);
+        return;
+    }
+    using T = Tile64x128;
+    auto kern = conv_pool_kernel<T, CIN>;
+    const int NT = L.b * (L.H / 2) * ((L.W + 63) / 64);
+    SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(cout / T::BM, NT)), dim3(T::THREADS), smem_bytes<T>(), s,
+               packed + conv_w_off(gi), packed + conv_b_off(gi), X, Y2, L, L2, cout);
+}
+
 void launch_dense(const float* packed, const float* image, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    SPP_LAUNCH(hk, KID_CONV1A, s, conv1a_kernel, dim3((w.L1.ld + 255) / 256, w.L1.b), dim3(256), 0, s, image,
-               packed + PW_C1A_W, packed + PW_C1A_B, w.a1, w.L1);
-    launch_conv<64, 9>(0, KID_CONV1B, packed, w.a1, w.b1, w.L1, 1, s, hk);
-    launch_pool(w.b1, w.L1, w.a2, w.L2, 64, s, hk);
+    PadPlanes pp{w.a2, w.a3, w.a4, w.L2, w.L3, w.L4, 32};
+    SPP_LAUNCH(hk, KID_CONV1A, s, conv1a_kernel, dim3((w.L1.ld + 255) / 256 + pp.nblocks, w.L1.b), dim3(256), 0, s, image,
+               packed + PW_C1A_W, packed + PW_C1A_B, w.a1, w.L1, pp);
+    launch_conv_pool<64>(0, KID_CONV1B, packed, w.a1, w.b1, w.a2, w.L1, w.L2, s, hk);     // conv1b + pool
     launch_conv<64, 9>(1, KID_CONV2, packed, w.a2, w.b2, w.L2, 1, s, hk);
-    launch_conv<64, 9>(2, KID_CONV2, packed, w.b2, w.a2, w.L2, 1, s, hk);
-    launch_pool(w.a2, w.L2, w.a3, w.L3, 64, s, hk);
+    launch_conv_pool<64>(2, KID_CONV2, packed, w.b2, w.a2, w.a3, w.L2, w.L3, s, hk);      // conv2b + pool (a2 is free: scratch)
     launch_conv<64, 9>(3, KID_CONV3A, packed, w.a3, w.b3, w.L3, 1, s, hk);
-    launch_conv<128, 9>(4, KID_CONV3B, packed, w.b3, w.c3, w.L3, 1, s, hk);
-    launch_pool(w.c3, w.L3, w.a4, w.L4, 128, s, hk);
+    launch_conv_pool<128>(4, KID_CONV3B, packed, w.b3, w.c3, w.a4, w.L3, w.L4, s, hk);    // conv3b + pool
     launch_conv<128, 9>(5, KID_CONV4, packed, w.a4, w.b4, w.L4, 1, s, hk);
     launch_conv<128, 9>(6, KID_CONV4, packed, w.b4, w.a4, w.L4, 1, s, hk);
     launch_conv<128, 9>(7, KID_HEADS, packed, w.a4, w.hd, w.L4, 1, s, hk);                                  // relu(convPa), relu(convDa)
