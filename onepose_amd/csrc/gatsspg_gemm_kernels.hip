@@ -20,7 +20,7 @@ using QkvTile = GemmTile<128, QKV_BN, 2, 2, false>;
 
 __global__ __launch_bounds__(256) void qkv_kv_kernel(const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
                                                      const float* __restrict__ Z, float* __restrict__ Qbuf,
-                                                     float* __restrict__ kvpart, ColLayout L) {
+                                                     float* __restrict__ kvpart, ColLayout L, int vec_store) {
     using T = QkvTile;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int rt, ct;
@@ -37,6 +37,11 @@ __global__ __launch_bounds__(256) void qkv_kv_kernel(const float* __restrict__ W
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    if (rt < 2 && vec_store) {
+        const float* bq = bqkv + rt * 128;
+        store_tile_via_lds<T>(acc, smem, Qbuf + (size_t)rt * 128 * ld + c0, ld, [&](int row, float v) { return elu1(v + bq[row]) + 1.f; });
+        return;
+    }
     if (rt < 2) {
 #pragma unroll
         for (int tm = 0; tm < T::TM; ++tm)
@@ -200,7 +205,7 @@ template <class T, int ABL = 0>
 __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                    const float* __restrict__ Z, const float* __restrict__ MSG,
                                                    float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
-                                                   unsigned long long* trace) {
+                                                   unsigned long long* trace, int vec_store) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned long long t_entry = trace ? wall_clock64() : 0;
     const unsigned long long c_entry = trace ? clock64() : 0;
@@ -234,10 +239,18 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
                 const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);
                 const int col = (wn * T::TN + tn) * 32 + l31;
                 const float v = acc[tm][tn][r] + b0[rt * T::BM + row];
-                U[(size_t)(rt * T::BM + row) * ld + c0 + col] = v;
+                if (!vec_store) U[(size_t)(rt * T::BM + row) * ld + c0 + col] = v;
                 Tl[row * TS + col] = v;
             }
     __syncthreads();
+    if (vec_store) {   // the tile leaves through LDS as 16-byte stores: 16 lanes cover one 256-byte row segment
+        for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
+            const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
+            const float* t = Tl + row * TS + c4;
+            vf4 v = {t[0], t[1], t[2], t[3]};
+            *reinterpret_cast<vf4*>(U + (size_t)(rt * T::BM + row) * ld + c0 + c4) = v;
+        }
+    }
     {   // per-row (sum, centred sum of squares) of this tile's real columns: 256 / BM lanes per row, each a fixed
         // contiguous column range, combined by shuffles (fixed order).  One pass, shifted by the row's first column
         // (a pivot within a few std of the mean), so M2 = sum d^2 - (sum d)^2 / n does not cancel even when
@@ -333,7 +346,7 @@ using Mlp3TileWide = GemmTile<64, 128, 1, 4, false>;
 template <class T, int ABL = 0>
 __global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
                                                    const float* __restrict__ U, const float* __restrict__ stats,
-                                                   float* __restrict__ Z, ColLayout L) {
+                                                   float* __restrict__ Z, ColLayout L, int vec_store) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int rt, ct;
     constexpr int MT = 256 / T::BM;
@@ -371,6 +384,10 @@ __global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ W3,
     };
     gemm_mainloop_ex<T, decltype(al), decltype(bl), decltype(xm), decltype(xr), decltype(bx), true, ABL>(
         acc, smem, 512 / BK, al, 512, bl, ld, xm, xr, bx);
+    if (vec_store) {
+        store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [](int, float v) { return v; });
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -562,11 +579,22 @@ void allow_big_lds(K kernel) {
 }
 #define GATSSPG_BIG_LDS_ONCE(kernel) allow_big_lds(kernel)
 
+// tuning knobs (read once): GATSSPG_MLP0_TILE / GATSSPG_MLP3_TILE select tile shapes, GATSSPG_VSTORE=0 switches the GEMM
+// epilogues back to 4-byte stores straight from the accumulators (default: 16-byte stores through an LDS tile)
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static int vec_store_enabled() {
+    static const int v = env_int("GATSSPG_VSTORE", 1);
+    return v;
+}
+
 void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     const int NT = active_tiles(w.L);
     GATSSPG_BIG_LDS_ONCE(qkv_kv_kernel);
     GATSSPG_LAUNCH(hk, KID_QKV_KV, s, qkv_kv_kernel, dim3(xcd_grid(6, NT)), dim3(256),
-                   shaped_lds(smem_bytes<QkvTile>(), 6 * NT), s, Wqkv, bqkv, w.Z, w.Q, w.kvpart, w.L);
+                   shaped_lds(smem_bytes<QkvTile>(), 6 * NT), s, Wqkv, bqkv, w.Z, w.Q, w.kvpart, w.L, vec_store_enabled());
     GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3(KVP / 64, w.nseg * H), dim3(1024), 0, s, w.kvpart,
                    w.kvfin, w.L);
 }
@@ -578,19 +606,16 @@ void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook
                    shaped_lds(smem_bytes<ApplyTile>(), NT * H), s, w.kvfin, w.Q, w.MSG, w.L, cross);
 }
 
-// tile selection: GATSSPG_MLP0_TILE / GATSSPG_MLP3_TILE (tuning knobs, read once)
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 
 template <class T, int ABL = 0>
 static void launch_mlp0_t(const float* W0, const float* b0, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     auto kern = mlp0_kernel<T, ABL>;
     GATSSPG_BIG_LDS_ONCE(kern);
+    const int vec_store = vec_store_enabled();
     const int NT = active_tiles(w.L);
     GATSSPG_LAUNCH(hk, KID_MLP0, s, kern, dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
-                   shaped_lds(smem_bytes<T>(), 512 / T::BM * NT), s, W0, b0, w.Z, w.MSG, w.U, w.statpart, w.L, g_trace);
+                   shaped_lds(smem_bytes<T>(), 512 / T::BM * NT), s, W0, b0, w.Z, w.MSG, w.U, w.statpart, w.L, g_trace,
+                   vec_store);
 }
 template <class T, int ABL = 0>
 static void launch_mlp3_t(const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk) {
@@ -598,7 +623,7 @@ static void launch_mlp3_t(const float* W3, const float* b3, const Workspace& w, 
     GATSSPG_BIG_LDS_ONCE(kern);
     const int NT = active_tiles(w.L) / (T::BN / 64);
     GATSSPG_LAUNCH(hk, KID_MLP3, s, kern, dim3(xcd_grid(256 / T::BM, NT)), dim3(256),
-                   shaped_lds(smem_bytes<T>(), 256 / T::BM * NT), s, W3, b3, w.U, w.stats, w.Z, w.L);
+                   shaped_lds(smem_bytes<T>(), 256 / T::BM * NT), s, W3, b3, w.U, w.stats, w.Z, w.L, vec_store_enabled());
 }
 
 void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const Workspace& w, hipStream_t s,

@@ -300,6 +300,32 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float
         acc, smem, KT, a_slab, lda, b_slab, ldb, nox, nox, NoXform(), bcol);
 }
 
+// Epilogue helper: the accumulator tile leaves through LDS as 16-byte stores (16 lanes cover one 256-byte row segment
+// of a 64-column tile) instead of 4-byte stores straight from the MFMA layout (measured on mlp0: -3 %).
+// f(row, v) is applied on the way in; dst points at the tile origin, ld is its row stride; both 16-byte aligned.
+// smem must be free (the main loop ends on a barrier) and hold BM * (BN + 4) floats.
+template <class T, class F>
+__device__ __forceinline__ void store_tile_via_lds(const f32x16 (&acc)[T::TM][T::TN], float* smem, float* dst, int ld, F f) {
+    constexpr int TS = T::BN + 4;
+    static_assert(T::BM * TS <= T::SMEM_FLOATS, "staging tile must fit the operand buffers");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);
+                smem[row * TS + (wn * T::TN + tn) * 32 + l31] = f(row, acc[tm][tn][r]);
+            }
+    __syncthreads();
+    for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
+        const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
+        *reinterpret_cast<vf4*>(dst + (size_t)row * ld + c4) = *reinterpret_cast<const vf4*>(smem + row * TS + c4);
+    }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
 #pragma unroll

@@ -33,8 +33,9 @@ __host__ __device__ inline bool feat_valid(const FeatLayout& L, int q, int& y, i
     y = q / L.Wp; x = q - y * L.Wp;
     return q < L.plane && y >= 1 && y <= L.H && x >= 1 && x <= L.W;
 }
-// floats of slack before the first / after the last channel row: shifted views reach Wp + 1 columns outside
-__host__ __device__ inline size_t feat_guard(const FeatLayout& L) { return (size_t)round_up(L.Wp + 8, 64); }
+// floats of slack before the first / after the last channel row: shifted views reach Wp + 1 columns outside a
+// flat tile, and the second row of a patch tile below an odd-height image reaches 2 * Wp + 1
+__host__ __device__ inline size_t feat_guard(const FeatLayout& L) { return (size_t)round_up(2 * L.Wp + 8, 64); }
 
 // ---- packed weights (floats) ---------------------------------------------------------------------------
 // GEMM convolutions, forward order; weights [rows][taps * cin] with k = tap * cin + ci, tap = 3*(dy+1) + (dx+1)

@@ -25,7 +25,7 @@ constexpr size_t smem_bytes() { return sizeof(float) * T::SMEM_FLOATS; }
 // =====================================================================================================
 // conv1a + ReLU (:142): one thread per padded position, all 64 output channels
 // =====================================================================================================
-// zero the one-pixel pad ring of every channel plane of P (the fused conv+pool epilogues write pixels only)
+// zero the one-pixel pad ring of every channel plane of P (the patch-tiled convolutions write pixels only)
 __device__ void zero_pad_ring(float* __restrict__ P, const FeatLayout& L, int C, int worker, int nworkers) {
     const int ring = 2 * L.Wp + 2 * L.H;                 // top row, bottom row, left + right columns
     const long long total = (long long)C * L.b * ring;
@@ -45,8 +45,10 @@ __device__ void zero_pad_ring(float* __restrict__ P, const FeatLayout& L, int C,
 }
 
 struct PadPlanes {
-    float *p2, *p3, *p4;
-    FeatLayout L2, L3, L4;
+    static constexpr int N = 6;
+    float* p[N];
+    FeatLayout L[N];
+    int C[N];
     int nblocks;      // workgroups of conv1a_kernel (after the image ones) that do this
 };
 
@@ -57,9 +59,8 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ i
     if ((int)blockIdx.x >= img_blocks) {
         if (blockIdx.y == 0) {
             const int worker = (blockIdx.x - img_blocks) * 256 + threadIdx.x, nworkers = pp.nblocks * 256;
-            zero_pad_ring(pp.p2, pp.L2, 64, worker, nworkers);
-            zero_pad_ring(pp.p3, pp.L3, 64, worker, nworkers);
-            zero_pad_ring(pp.p4, pp.L4, 128, worker, nworkers);
+#pragma unroll
+            for (int i = 0; i < PadPlanes::N; ++i) zero_pad_ring(pp.p[i], pp.L[i], pp.C[i], worker, nworkers);
         }
         return;
     }
@@ -97,18 +98,32 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ i
 
 // =====================================================================================================
 // 3x3 / 1x1 convolution + bias (+ ReLU) as an implicit GEMM.  Wt [rows][TAPS*CIN] (k = tap*CIN + ci),
-// X [CIN][ldt] -> Y [cout][ldt]; pad positions of Y are written as zeros.
+// X [CIN][ldt] -> Y [cout][ldt].
+//   PATCH = false: the BN columns of a workgroup are BN consecutive positions of the flattened padded plane (pad
+//                  positions included; they are written as zeros).  Used by the 1x1 convolutions.
+//   PATCH = true : the BN columns are a 2-row x BN/2-pixel image patch (column map of the main loop): the three dy taps
+//                  of the two rows touch 4 input rows instead of 6, i.e. a third fewer L1-missing bytes per MFMA, which
+//                  is what the main loop is sensitive to.  Only pixels are written; the pad ring of the output plane is
+//                  zeroed once per forward by conv1a_kernel's extra workgroups.
 // =====================================================================================================
-template <class T, int CIN, int TAPS>
+struct PatchCol {
+    int half, Wp;     // half = pixels per patch row (BN / 2)
+    __device__ __forceinline__ int operator()(int c) const { return c < half ? c : c - half + Wp; }
+};
+
+template <class T, int CIN, int TAPS, bool PATCH>
 __global__ __launch_bounds__(T::THREADS) void conv_gemm_kernel(const float* __restrict__ Wt, const float* __restrict__ bias,
-                                                        const float* __restrict__ X, float* __restrict__ Y, FeatLayout L,
-                                                        int cout, int relu) {
+                                                               const float* __restrict__ X, float* __restrict__ Y, FeatLayout L,
+                                                               int cout, int relu) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CPS = CIN / BK;            // K slabs per tap
     constexpr int KT = TAPS * CPS;
+    constexpr int HALF = T::BN / 2;
     static_assert(KT % 2 == 0, "the main loop consumes slabs in pairs");
+    static_assert(!PATCH || TAPS == 9, "patch tiling is for the 3x3 convolutions");
+    const int SEG = (L.W + HALF - 1) / HALF, HP = (L.H + 1) / 2;   // H is odd at 1/8 resolution when H/8 is
     const int MT = (cout + T::BM - 1) / T::BM;
-    const int NT = L.ldt / T::BN;
+    const int NT = PATCH ? L.b * HP * SEG : L.ldt / T::BN;
     // XCD-aware tile map (workgroup g runs on XCD g % 8): every XCD owns one contiguous band of column tiles, i.e. a
     // band of image rows, and walks it top to bottom with the row tiles of a column tile back to back.  The dy = +-1 taps
     // of a tile read the rows of the tiles one image row above / below; with bands those are in the same XCD's L2
@@ -118,7 +133,17 @@ __global__ __launch_bounds__(T::THREADS) void conv_gemm_kernel(const float* __re
     const int rt = slot % MT;
     const int ct = (blockIdx.x & 7) * per + slot / MT;
     if (slot / MT >= per || ct >= NT) return;
-    const int c0 = ct * T::BN, ldt = L.ldt, Wp = L.Wp;
+    const int ldt = L.ldt, Wp = L.Wp;
+    int c0, im = 0, sx = 0, yp = 0;
+    if constexpr (PATCH) {
+        im = ct / (HP * SEG);
+        const int r = ct - im * (HP * SEG);
+        yp = r / SEG;
+        sx = r - yp * SEG;
+        c0 = im * L.ld + (1 + 2 * yp) * Wp + 1 + HALF * sx;
+    } else {
+        c0 = ct * T::BN;
+    }
     const float* A = Wt + (size_t)rt * T::BM * (TAPS * CIN);
     f32x16 acc[T::TM][T::TN];
     gatsspg::zero_acc(acc);
@@ -128,22 +153,32 @@ __global__ __launch_bounds__(T::THREADS) void conv_gemm_kernel(const float* __re
         const int shift = TAPS == 9 ? (tap / 3 - 1) * Wp + (tap % 3 - 1) : 0;
         return X + ((ptrdiff_t)cc * BK * ldt + c0 + shift);
     };
-    gatsspg::gemm_mainloop<T>(acc, smem, KT, al, TAPS * CIN, bl, ldt);
+    if constexpr (PATCH) gatsspg::gemm_mainloop<T, decltype(al), decltype(bl), 0, PatchCol>(acc, smem, KT, al, TAPS * CIN, bl, ldt, PatchCol{HALF, Wp});
+    else gatsspg::gemm_mainloop<T>(acc, smem, KT, al, TAPS * CIN, bl, ldt);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int tn = 0; tn < T::TN; ++tn) {
-        const int col = c0 + (wn * T::TN + tn) * 32 + l31;
-        const int q = col % L.ld;
-        int y, x;
-        const bool ok = feat_valid(L, q, y, x);
+        const int tc = (wn * T::TN + tn) * 32 + l31;     // column inside the tile
+        int col;
+        bool ok, store;
+        if constexpr (PATCH) {
+            const int prow = tc / HALF, px = tc - prow * HALF;
+            col = c0 + prow * Wp + px;
+            ok = store = HALF * sx + px < L.W && 2 * yp + prow < L.H;
+        } else {
+            col = c0 + tc;
+            int y, x;
+            ok = feat_valid(L, col % L.ld, y, x);
+            store = true;
+        }
 #pragma unroll
         for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * T::BM + (wm * T::TM + tm) * 32 + mfma_row(r, half);
-                if (row < cout) {
+                if (row < cout && store) {
                     float v = acc[tm][tn][r] + bias[row];
                     if (relu) v = fmaxf(v, 0.f);
                     Y[(size_t)row * ldt + col] = ok ? v : 0.f;
@@ -159,11 +194,6 @@ __global__ __launch_bounds__(T::THREADS) void conv_gemm_kernel(const float* __re
 // written (conv1b: 67.7 MB less HBM traffic, one launch less per resolution).  Y2 is the half-resolution padded plane;
 // only its pixels are written (its pad ring is zeroed once per forward by conv1a_kernel's extra workgroups).
 // =====================================================================================================
-struct PatchCol {
-    int Wp;
-    __device__ __forceinline__ int operator()(int c) const { return (c & 63) + (c >> 6) * Wp; }
-};
-
 template <class T, int CIN>
 __global__ __launch_bounds__(T::THREADS) void conv_pool_kernel(const float* __restrict__ Wt, const float* __restrict__ bias,
                                                                const float* __restrict__ X, float* __restrict__ Y2, FeatLayout L,
@@ -191,7 +221,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_pool_kernel(const float* __re
         const int tap = kt / CPS, cc = kt - tap * CPS;
         return X + ((ptrdiff_t)cc * BK * ldt + c0 + (tap / 3 - 1) * Wp + (tap % 3 - 1));
     };
-    gatsspg::gemm_mainloop<T, decltype(al), decltype(bl), 0, PatchCol>(acc, smem, KT, al, 9 * CIN, bl, ldt, PatchCol{Wp});
+    gatsspg::gemm_mainloop<T, decltype(al), decltype(bl), 0, PatchCol>(acc, smem, KT, al, 9 * CIN, bl, ldt, PatchCol{64, Wp});
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
@@ -290,12 +320,27 @@ using Tile128x64 = GemmTile<128, 64, 2, 2, false, true>;
 using Tile64x128w8 = GemmTile<64, 128, 2, 4, false, true>;    // 8 waves, one 32x32 MFMA tile each
 using Tile128x64w8 = GemmTile<128, 64, 4, 2, false, true>;
 
+static bool patch_tiling() {
+    static const bool on = !(getenv("SPP_PATCH") && atoi(getenv("SPP_PATCH")) == 0);   // SPP_PATCH=0: flat tiles (A/B timing)
+    return on;
+}
+
 template <class T, int CIN, int TAPS>
 static void launch_conv_t(int gi, int kid, const float* packed, const float* X, float* Y, const FeatLayout& L, int relu,
                           hipStream_t s, ProfileHook* hk) {
-    auto kern = conv_gemm_kernel<T, CIN, TAPS>;
     const int cout = kConv[gi].cout;
-    const int MT = (cout + T::BM - 1) / T::BM, NT = L.ldt / T::BN;
+    const int MT = (cout + T::BM - 1) / T::BM;
+    if constexpr (TAPS == 9) {
+        if (patch_tiling()) {
+            auto kern = conv_gemm_kernel<T, CIN, TAPS, true>;
+            const int NT = L.b * ((L.H + 1) / 2) * ((L.W + T::BN / 2 - 1) / (T::BN / 2));
+            SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(MT, NT)), dim3(T::THREADS), smem_bytes<T>(), s,
+                       packed + conv_w_off(gi), packed + conv_b_off(gi), X, Y, L, cout, relu);
+            return;
+        }
+    }
+    auto kern = conv_gemm_kernel<T, CIN, TAPS, false>;
+    const int NT = L.ldt / T::BN;
     SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(MT, NT)), dim3(T::THREADS), smem_bytes<T>(), s, packed + conv_w_off(gi),
                packed + conv_b_off(gi), X, Y, L, cout, relu);
 }
@@ -355,7 +400,7 @@ static void launch_conv_pool(int gi, int kid, const float* packed, const float* 
 }
 
 void launch_dense(const float* packed, const float* image, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    PadPlanes pp{w.a2, w.a3, w.a4, w.L2, w.L3, w.L4, 32};
+    PadPlanes pp{{w.a2, w.b2, w.a3, w.b3, w.a4, w.b4}, {w.L2, w.L2, w.L3, w.L3, w.L4, w.L4}, {64, 64, 64, 128, 128, 128}, 32};
     SPP_LAUNCH(hk, KID_CONV1A, s, conv1a_kernel, dim3((w.L1.ld + 255) / 256 + pp.nblocks, w.L1.b), dim3(256), 0, s, image,
                packed + PW_C1A_W, packed + PW_C1A_B, w.a1, w.L1, pp);
     launch_conv_pool<64>(0, KID_CONV1B, packed, w.a1, w.b1, w.a2, w.L1, w.L2, s, hk);     // conv1b + pool
