@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
 using Mlp0Tile = GemmTile<128, MLP0_BN, 2, 2, false>;
 using Mlp0TileWide = GemmTile<256, MLP0_BN, 4, 1, false>;
 using Mlp0TileW8 = GemmTile<128, MLP0_BN, 4, 2, false>;    // 8 waves, one 32x32 MFMA tile each
+using Mlp0TileBig = GemmTile<128, 2 * MLP0_BN, 2, 4, false>;   // 8 waves, 128x128: a third fewer operand bytes per MFMA
 
 // per-workgroup timeline of mlp0_kernel (tools/trace_mlp0.py): 8 x u64 per workgroup
 // [hw_id, xcc_id, t_entry, shader cycles, t_after_mainloop, t_end, rt, ct], 100 MHz wall clock.
@@ -210,10 +211,10 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
     const unsigned long long t_entry = trace ? wall_clock64() : 0;
     const unsigned long long c_entry = trace ? clock64() : 0;
     int rt, ct;
-    static_assert(T::BN == 64, "tile windows are counted in 64-column tiles");
+    constexpr int TPW = T::BN / MLP0_BN;   // 64-column tiles (= InstanceNorm partials) per workgroup
     constexpr int MT = 512 / T::BM;
-    if (!xcd_tile_map(MT, active_tiles(L), rt, ct)) return;
-    ct = global_tile(L, ct);
+    if (!xcd_tile_map(MT, active_tiles(L) / TPW, rt, ct)) return;
+    ct = global_tile(L, ct * TPW) / TPW;   // windows and segments are multiples of 128 columns
     const int c0 = ct * T::BN, ld = L.ld;
     const float* A = W0 + (size_t)rt * T::BM * 512;
     f32x16 acc[T::TM][T::TN];
@@ -251,31 +252,35 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
             *reinterpret_cast<vf4*>(U + (size_t)(rt * T::BM + row) * ld + c0 + c4) = v;
         }
     }
-    {   // per-row (sum, centred sum of squares) of this tile's real columns: 256 / BM lanes per row, each a fixed
-        // contiguous column range, combined by shuffles (fixed order).  One pass, shifted by the row's first column
-        // (a pivot within a few std of the mean), so M2 = sum d^2 - (sum d)^2 / n does not cancel even when
-        // |mean| >> std; stat_final merges the tiles with Chan's formula.
-        constexpr int LPR = T::THREADS / T::BM;    // lanes per row (2 for BM=128, 1 for BM=256 on 4 waves)
-        constexpr int CPL = T::BN / LPR;           // columns per lane
-        const int row = tid / LPR, part = tid % LPR;
-        const float pivot = Tl[row * TS];
-        const float* tr = Tl + row * TS + part * CPL;
+    {   // per-row (sum, centred sum of squares) of the real columns of each 64-column tile: THREADS / BM lanes per row,
+        // each a fixed contiguous column range, combined by shuffles (fixed order).  One pass, shifted by the first
+        // column of the row (a pivot within a few std of the mean), so M2 = sum d^2 - (sum d)^2 / n does not cancel even
+        // when |mean| >> std; stat_final merges the tiles with Chan's formula.
+        constexpr int LPR = T::THREADS / T::BM;    // lanes per row
+        constexpr int LPS = LPR / TPW;             // lanes per (row, 64-column tile)
+        constexpr int CPL = MLP0_BN / LPS;         // columns per lane
+        static_assert(LPS >= 1, "at least one lane per row and 64-column tile");
+        const int row = tid / LPR, q = tid % LPR, sub = q / LPS, part = q % LPS;
+        const int valid = min(max(ts.valid - sub * MLP0_BN, 0), MLP0_BN);
+        const float pivot = Tl[row * TS + sub * MLP0_BN];
+        const float* tr = Tl + row * TS + sub * MLP0_BN + part * CPL;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll 8
         for (int m = 0; m < CPL; ++m) {
-            const float d = (part * CPL + m < ts.valid) ? tr[m] - pivot : 0.f;
+            const float d = (part * CPL + m < valid) ? tr[m] - pivot : 0.f;
             s1 += d;
             s2 += d * d;
         }
 #pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) {
+        for (int o = 1; o < LPS; o <<= 1) {
             s1 += __shfl_xor(s1, o);
             s2 += __shfl_xor(s2, o);
         }
         if (part == 0) {
-            const float nv = (float)ts.valid;
-            statpart[((size_t)ct * 2 + 0) * 512 + rt * T::BM + row] = nv * pivot + s1;                       // sum
-            statpart[((size_t)ct * 2 + 1) * 512 + rt * T::BM + row] = nv > 0.f ? s2 - s1 * s1 / nv : 0.f;    // M2
+            const float nv = (float)valid;
+            const size_t t64 = (size_t)ct * TPW + sub;
+            statpart[(t64 * 2 + 0) * 512 + rt * T::BM + row] = nv * pivot + s1;                       // sum
+            statpart[(t64 * 2 + 1) * 512 + rt * T::BM + row] = nv > 0.f ? s2 - s1 * s1 / nv : 0.f;    // M2
         }
     }
     if (trace && tid == 0) {
@@ -612,7 +617,7 @@ static void launch_mlp0_t(const float* W0, const float* b0, const Workspace& w, 
     auto kern = mlp0_kernel<T, ABL>;
     GATSSPG_BIG_LDS_ONCE(kern);
     const int vec_store = vec_store_enabled();
-    const int NT = active_tiles(w.L);
+    const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
     GATSSPG_LAUNCH(hk, KID_MLP0, s, kern, dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
                    shaped_lds(smem_bytes<T>(), 512 / T::BM * NT), s, W0, b0, w.Z, w.MSG, w.U, w.statpart, w.L, g_trace,
                    vec_store);
@@ -630,7 +635,9 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
                 ProfileHook* hk) {
     // GATSSPG_MLP0_TILE / GATSSPG_MLP3_TILE select alternative (equally correct) tile shapes; the
     // ablation variants (wrong results, timing only) exist only in a -DGATSSPG_PROFILING_BUILD library.
-    static const int t0 = env_int("GATSSPG_MLP0_TILE", 0), t3 = env_int("GATSSPG_MLP3_TILE", 0);
+    // mlp0 default: 128x64 on 8 waves (one 32x32 MFMA tile per wave; measured 43.1 us vs 45.0 us for the 4-wave
+    // form of the same tile, 45.6 us for 128x128 on 8 waves).
+    static const int t0 = env_int("GATSSPG_MLP0_TILE", 2), t3 = env_int("GATSSPG_MLP3_TILE", 0);
 #ifdef GATSSPG_PROFILING_BUILD
     if (t0 == 11) launch_mlp0_t<Mlp0Tile, 1>(W0, b0, w, s, hk);        // no global loads in the loop
     else if (t0 == 12) launch_mlp0_t<Mlp0Tile, 2>(W0, b0, w, s, hk);   // no loads, no LDS writes
@@ -640,6 +647,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
 #endif
     if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
     else if (t0 == 2) launch_mlp0_t<Mlp0TileW8>(W0, b0, w, s, hk);
+    else if (t0 == 3) launch_mlp0_t<Mlp0TileBig>(W0, b0, w, s, hk);
     else launch_mlp0_t<Mlp0Tile>(W0, b0, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
 #ifdef GATSSPG_PROFILING_BUILD
