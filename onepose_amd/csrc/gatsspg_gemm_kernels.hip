@@ -348,9 +348,11 @@ __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restric
 using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;
 using Mlp3TileTall = GemmTile<128, 64, 2, 2, false>;
 using Mlp3TileWide = GemmTile<64, 128, 1, 4, false>;
+using Mlp3TileTallW8 = GemmTile<128, 64, 4, 2, false>;   // 8 waves
+using Mlp3TileWideW8 = GemmTile<64, 128, 2, 4, false>;   // 8 waves
 
 template <class T, int ABL = 0>
-__global__ __launch_bounds__(256) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
+__global__ __launch_bounds__(T::THREADS) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
                                                    const float* __restrict__ U, const float* __restrict__ stats,
                                                    float* __restrict__ Z, ColLayout L, int vec_store) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -636,7 +638,7 @@ static void launch_mlp3_t(const float* W3, const float* b3, const Workspace& w, 
     auto kern = mlp3_kernel<T, ABL>;
     GATSSPG_BIG_LDS_ONCE(kern);
     const int NT = active_tiles(w.L) / (T::BN / 64);
-    GATSSPG_LAUNCH(hk, KID_MLP3, s, kern, dim3(xcd_grid(256 / T::BM, NT)), dim3(256),
+    GATSSPG_LAUNCH(hk, KID_MLP3, s, kern, dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS),
                    shaped_lds(smem_bytes<T>(), 256 / T::BM * NT), s, W3, b3, w.U, w.stats, w.Z, w.L, vec_store_enabled());
 }
 
@@ -667,6 +669,8 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
 #endif
     if (t3 == 1) launch_mlp3_t<Mlp3TileTall>(W3, b3, w, s, hk);
     else if (t3 == 2) launch_mlp3_t<Mlp3TileWide>(W3, b3, w, s, hk);
+    else if (t3 == 3) launch_mlp3_t<Mlp3TileTallW8>(W3, b3, w, s, hk);
+    else if (t3 == 4) launch_mlp3_t<Mlp3TileWideW8>(W3, b3, w, s, hk);
     else launch_mlp3_t<Mlp3Tile>(W3, b3, w, s, hk);
 }
 

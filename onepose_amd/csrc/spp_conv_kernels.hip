@@ -28,11 +28,10 @@ constexpr size_t smem_bytes() { return sizeof(float) * T::SMEM_FLOATS; }
 // zero the one-pixel pad ring of every channel plane of P (the patch-tiled convolutions write pixels only)
 __device__ void zero_pad_ring(float* __restrict__ P, const FeatLayout& L, int C, int worker, int nworkers) {
     const int ring = 2 * L.Wp + 2 * L.H;                 // top row, bottom row, left + right columns
-    const long long total = (long long)C * L.b * ring;
-    for (long long i = worker; i < total; i += nworkers) {
-        const int r = (int)(i % ring);
-        const long long ci = i / ring;
-        const int im = (int)(ci % L.b), c = (int)(ci / L.b);
+    const int total = C * L.b * ring;                    // < 2^31: C * b * ring <= 512 * b * 2056
+    for (int i = worker; i < total; i += nworkers) {
+        const int ci = i / ring, r = i - ci * ring;
+        const int c = ci / L.b, im = ci - c * L.b;
         int q;
         if (r < L.Wp) q = r;                                                   // y = 0
         else if (r < 2 * L.Wp) q = (L.H + 1) * L.Wp + (r - L.Wp);              // y = H + 1
@@ -400,7 +399,7 @@ static void launch_conv_pool(int gi, int kid, const float* packed, const float* 
 }
 
 void launch_dense(const float* packed, const float* image, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    PadPlanes pp{{w.a2, w.b2, w.a3, w.b3, w.a4, w.b4}, {w.L2, w.L2, w.L3, w.L3, w.L4, w.L4}, {64, 64, 64, 128, 128, 128}, 32};
+    PadPlanes pp{{w.a2, w.b2, w.a3, w.b3, w.a4, w.b4}, {w.L2, w.L2, w.L3, w.L3, w.L4, w.L4}, {64, 64, 64, 128, 128, 128}, 192};
     SPP_LAUNCH(hk, KID_CONV1A, s, conv1a_kernel, dim3((w.L1.ld + 255) / 256 + pp.nblocks, w.L1.b), dim3(256), 0, s, image,
                packed + PW_C1A_W, packed + PW_C1A_B, w.a1, w.L1, pp);
     launch_conv_pool<64>(0, KID_CONV1B, packed, w.a1, w.b1, w.a2, w.L1, w.L2, s, hk);     // conv1b + pool
