@@ -13,9 +13,10 @@
  * never allocates and never synchronises; functions return 0 on success or a negative code, with
  * text available from spp_last_error().
  *
- * Shapes: image [b][1][H][W] grayscale in [0,1], H and W multiples of 8 (three 2x2 poolings and
- * the 8x8 cell shuffle, :145-151,160-162).  descriptor_dim is 256 (the reference default, :105,
- * and what the matcher consumes).
+ * Shapes: image [b][1][H][W] grayscale in [0,1], H, W >= 8.  Hc = H/8, Wc = W/8 (integer division:
+ * three floor-mode 2x2 poolings, :145-151); the score map and every keypoint live in the
+ * Hs x Ws = (8*Hc) x (8*Wc) top-left part of the image (:160-162), exactly as in the reference.
+ * descriptor_dim is 256 (the reference default, :105, and what the matcher consumes).
  */
 #ifndef ONEPOSE_AMD_SUPERPOINT_H
 #define ONEPOSE_AMD_SUPERPOINT_H
@@ -52,8 +53,8 @@ int spp_pack_weights(const spp_raw_weights* raw, float* packed, spp_stream_t str
 
 size_t spp_workspace_bytes(int b, int H, int W);
 
-/* Dense stages (:142-162,183-184): image -> score_map [b][H][W] (cell softmax, dustbin dropped, 8x8
- * shuffle; BEFORE nms) and dense_desc [b][256][H/8][W/8] (convDb output, NOT normalised). */
+/* Dense stages (:142-162,183-184): image -> score_map [b][Hs][Ws] (cell softmax, dustbin dropped, 8x8
+ * shuffle; BEFORE nms) and dense_desc [b][256][Hc][Wc] (convDb output, NOT normalised). */
 int spp_dense(const float* packed, const float* image, int b, int H, int W, float* score_map, float* dense_desc,
               void* workspace, size_t workspace_bytes, spp_stream_t stream);
 
@@ -71,7 +72,7 @@ int spp_dense(const float* packed, const float* image, int b, int H, int W, floa
  *                  builds OnePose pins, 0 is what the same line yields on torch >= 1.10 / 2.x. */
 int spp_detect(const float* score_map, const float* dense_desc, int b, int H, int W, int nms_radius,
                float keypoint_threshold, int max_keypoints, int remove_borders, int align_corners, int capacity,
-               float* keypoints, float* scores, float* descriptors, int32_t* counts, float* nms_out /* optional [b][H][W] */,
+               float* keypoints, float* scores, float* descriptors, int32_t* counts, float* nms_out /* optional [b][Hs][Ws] */,
                void* workspace, size_t workspace_bytes, spp_stream_t stream);
 
 /* SuperPoint.forward: spp_dense + spp_detect without the intermediate copies. */

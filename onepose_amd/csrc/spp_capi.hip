@@ -23,8 +23,8 @@ int fail(const char* fmt, ...) {
 
 int check_dims(int b, int H, int W) {
     if (b < 1) return fail("batch must be >= 1 (got %d)", b);
-    if (H < 8 || W < 8 || (H & 7) || (W & 7))
-        return fail("H and W must be positive multiples of 8 (three 2x2 poolings + the 8x8 cell shuffle); got %dx%d", H, W);
+    if (H < 8 || W < 8)   // three floor-mode 2x2 poolings must leave at least one 8x8 cell
+        return fail("H and W must be >= 8; got %dx%d", H, W);
     const long long cols = (long long)b * (((long long)(H + 2) * (W + 2) + 127) / 128 * 128);
     if (cols * 32 * 4 >= (1ll << 32)) return fail("problem too large: b*(H+2)*(W+2) = %lld columns", cols);
     return 0;
@@ -121,7 +121,7 @@ int spp_detect(const float* score_map, const float* dense_desc, int b, int H, in
     if (int e = check_detect(nms_radius, max_keypoints, remove_borders, capacity, dp, keypoint_threshold, align_corners)) return e;
     if (!score_map || !dense_desc || !keypoints || !scores || !descriptors || !counts) return fail("null argument");
     DescView v;
-    const int Hc = H / 8, Wc = W / 8;
+    const int Hc = H / 8, Wc = W / 8;   // floor: what three MaxPool2d(2, 2) leave
     v.p = dense_desc; v.cstride = (size_t)Hc * Wc; v.istride = (size_t)DD * Hc * Wc; v.rstride = Wc; v.origin = 0;
     launch_detect(score_map, v, w, dp, keypoints, scores, descriptors, counts, nms_out, reinterpret_cast<hipStream_t>(stream),
                   nullptr);

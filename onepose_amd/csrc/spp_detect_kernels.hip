@@ -496,7 +496,8 @@ void launch_score_map(const Workspace& w, float* score_map, hipStream_t s, Profi
 
 void launch_detect(const float* score_map, DescView dv, const Workspace& w, const DetectParams& dp, float* keypoints,
                    float* scores, float* descriptors, int32_t* counts, float* nms_out, hipStream_t s, ProfileHook* hk) {
-    const int b = w.L1.b, H = w.L1.H, W = w.L1.W, Hc = w.L4.H, Wc = w.L4.W;
+    // the score map covers the (H/8)*8 x (W/8)*8 top-left part of the image (:160-162: h*8, w*8 after three floor poolings)
+    const int b = w.L1.b, Hc = w.L4.H, Wc = w.L4.W, H = Hc * 8, W = Wc * 8;
     float* nms = nms_out ? nms_out : w.nms;
     const int R = dp.nms_radius;
     if (R == 0) {

@@ -82,7 +82,7 @@ class SuperPointEngine:
         b, _, h, w = image.shape
         dev = image.device
         ws = self.workspace(b, h, w, dev)
-        score = torch.empty(b, h, w, device=dev, dtype=torch.float32)
+        score = torch.empty(b, h // 8 * 8, w // 8 * 8, device=dev, dtype=torch.float32)
         dense = torch.empty(b, 256, h // 8, w // 8, device=dev, dtype=torch.float32)
         _native_spp.check(self.lib.spp_dense(self.packed_weights(dev).data_ptr(), image.data_ptr(), b, h, w, score.data_ptr(),
                                              dense.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "spp_dense")

@@ -46,6 +46,8 @@ CASES = {
     # no NMS, higher threshold, no border removal
     "r0_thr": dict(wseed=6, img=dict(b=1, h=64, w=80, seed=7),
                    cfg={"nms_radius": 0, "keypoint_threshold": 0.05, "remove_borders": 0}, align=True, store="full"),
+    # sizes that are not multiples of 8: floor-mode poolings, keypoints only in the (h*8) x (w*8) top-left part (:160-162)
+    "odd_size": dict(wseed=8, img=dict(b=2, h=75, w=101, seed=9), cfg=PIPELINE_CFG, align=True, store="full"),
     # the pipeline's shape (512x512 crop, :extract_features.py:15-19)
     "crop512": dict(wseed=0, img=dict(b=1, h=512, w=512, seed=11), cfg=PIPELINE_CFG, align=True, store="sub"),
 }

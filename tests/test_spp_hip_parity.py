@@ -50,7 +50,7 @@ def match_rows(kp, gk):
     return p
 
 
-@pytest.mark.parametrize("name", ["tiny_default", "rect_pipeline", "r0_thr"])
+@pytest.mark.parametrize("name", ["tiny_default", "rect_pipeline", "r0_thr", "odd_size"])
 def test_dense_stages_vs_oracle_and_golden(name):
     m = META[name]
     mod, sd = make_module(m["wseed"], m["cfg"])
@@ -81,6 +81,7 @@ DETECT_CASES = [
     (136, 104, 5, 0.002, 8, -1, 5),
     (64, 64, 6, 0.0, 0, 7, 6),
     (256, 256, 3, 0.005, 4, 1000, 7),
+    (77, 123, 3, 0.005, 4, -1, 8),          # not multiples of 8: the score map is 72 x 120
 ]
 
 
@@ -134,7 +135,7 @@ def test_detect_ties_and_plateaus():
     assert n == 17
 
 
-@pytest.mark.parametrize("name", ["tiny_default", "rect_pipeline", "rect_noalign", "r0_thr", "topk50"])
+@pytest.mark.parametrize("name", ["tiny_default", "rect_pipeline", "rect_noalign", "r0_thr", "topk50", "odd_size"])
 def test_forward_vs_reference_golden(name):
     m = META[name]
     mod, _ = make_module(m["wseed"], m["cfg"], align=m["align"])
@@ -242,8 +243,8 @@ def test_extractor_feeds_matcher_on_device():
 def test_bad_arguments_raise():
     from onepose_amd._native import NativeError
     mod, _ = make_module(0, {})
-    with pytest.raises(NativeError, match="multiples of 8"):
-        mod(torch.zeros(1, 1, 60, 64).cuda())
+    with pytest.raises(NativeError, match=">= 8"):
+        mod(torch.zeros(1, 1, 7, 64).cuda())
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         mod(torch.zeros(1, 1, 64, 64))
     mod.config["nms_radius"] = 9
@@ -251,7 +252,7 @@ def test_bad_arguments_raise():
         mod(torch.zeros(1, 1, 64, 64).cuda())
 
 
-@pytest.mark.parametrize("b,h,w", [(1, 8, 8), (2, 8, 24), (1, 16, 512), (3, 40, 72)])
+@pytest.mark.parametrize("b,h,w", [(1, 8, 8), (2, 8, 24), (1, 16, 512), (3, 40, 72), (1, 15, 9), (2, 67, 130), (1, 129, 66)])
 def test_small_and_skinny_images_vs_oracle(b, h, w):
     """Smallest legal image (one 8x8 cell), single-cell rows, very skinny planes, odd batch."""
     cfg = {"nms_radius": 2, "remove_borders": 0, "keypoint_threshold": 0.001, "max_keypoints": -1}

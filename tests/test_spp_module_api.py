@@ -67,7 +67,8 @@ def test_every_declared_symbol_is_exported():
     assert lib.spp_packed_weights_bytes() == 4 * (64 * 9 + 64 + 64 + 3 * (64 * 576 + 64) + 128 * 576 + 128 + 3 * (128 * 1152 + 128)
                                                   + 512 * 1152 + 512 + 128 * 256 + 128 + 256 * 256 + 256)
     assert 0 < lib.spp_workspace_bytes(1, 64, 64) < lib.spp_workspace_bytes(1, 512, 512) < 2**28
-    assert lib.spp_workspace_bytes(1, 60, 64) == 0 and b"multiples of 8" in lib.spp_last_error()
+    assert lib.spp_workspace_bytes(1, 7, 64) == 0 and b">= 8" in lib.spp_last_error()
+    assert lib.spp_workspace_bytes(1, 75, 101) > 0        # any size >= 8: floor-mode poolings like the reference
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

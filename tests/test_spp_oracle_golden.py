@@ -39,7 +39,7 @@ def match_rows(kp, gk):
     return p
 
 
-@pytest.mark.parametrize("name", ["tiny_default", "rect_pipeline", "rect_noalign", "r0_thr"])
+@pytest.mark.parametrize("name", ["tiny_default", "rect_pipeline", "rect_noalign", "r0_thr", "odd_size"])
 def test_oracle_matches_reference(name):
     g = load(name)
     out, inter = run(name)
@@ -110,7 +110,7 @@ def test_select_ties_and_borders():
     assert [2, 8] in yx.tolist()
 
 
-@pytest.mark.parametrize("name", ["tiny_default", "rect_pipeline", "rect_noalign"])
+@pytest.mark.parametrize("name", ["tiny_default", "rect_pipeline", "rect_noalign", "odd_size"])
 def test_torch_restatement_matches_reference(name):
     """oracle/torch_superpoint_oracle.py (the stock-PyTorch baseline of bench.py --extractor --torch-eager)."""
     import torch
