@@ -463,11 +463,12 @@ __global__ __launch_bounds__(256) void final_proj_norm_kernel(const float* __res
 //     buffers that are reduced in a fixed order.
 // =====================================================================================================
 using ScoreTile = GemmTile<SC_BM, SC_BN, 2, 2, true>;
+using ScoreTileW8 = GemmTile<SC_BM, SC_BN, 4, 2, true>;    // same tile on 8 waves
 
-__global__ __launch_bounds__(256) void score_exp_kernel(const float* __restrict__ MD, float* __restrict__ conf,
-                                                        float* __restrict__ rowpart, float* __restrict__ colpart,
-                                                        ColLayout L, float scale) {
-    using T = ScoreTile;
+template <class T>
+__global__ __launch_bounds__(T::THREADS) void score_exp_kernel(const float* __restrict__ MD, float* __restrict__ conf,
+                                                               float* __restrict__ rowpart, float* __restrict__ colpart,
+                                                               ColLayout L, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nrt = L.n1p / T::BM, nct = L.n2p / T::BN;
     int rt, ct;
@@ -490,34 +491,56 @@ __global__ __launch_bounds__(256) void score_exp_kernel(const float* __restrict_
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = wm * 64 + tm * 32 + mfma_row(r, half);
+            const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);
             const int col = wn * 32 + l31;
             const int gi = rt * T::BM + row, gj = ct * T::BN + col;
-            float e = 0.f;
-            if (gi < L.n1 && gj < L.n2) {
-                e = expf(acc[tm][0][r] / scale);
-                cf[(size_t)gi * L.n2 + gj] = e;
-            }
-            Tl[row * TS + col] = e;
+            Tl[row * TS + col] = (gi < L.n1 && gj < L.n2) ? expf(acc[tm][0][r] / scale) : 0.f;
         }
     __syncthreads();
-    {   // row sums: 2 lanes per row (32 columns each); column sums: 4 lanes per column (32 rows each)
-        const int row = tid >> 1, hp = tid & 1;
-        const float* tr = Tl + row * TS + hp * 32;
+    // E leaves through the LDS tile: 16 lanes cover one 256-byte row segment (16-byte stores when the rows of conf are
+    // 16-byte aligned, i.e. n2 % 4 == 0; otherwise 4-byte stores, 64 lanes per row segment)
+    if ((L.n2 & 3) == 0) {
+        for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
+            const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
+            const int gi = rt * T::BM + row, gj = ct * T::BN + c4;
+            if (gi < L.n1 && gj < L.n2) {
+                const float* t = Tl + row * TS + c4;
+                vf4 v = {t[0], t[1], t[2], t[3]};
+                *reinterpret_cast<vf4*>(cf + (size_t)gi * L.n2 + gj) = v;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < T::BM * T::BN; idx += T::THREADS) {
+            const int row = idx / T::BN, col = idx % T::BN;
+            const int gi = rt * T::BM + row, gj = ct * T::BN + col;
+            if (gi < L.n1 && gj < L.n2) cf[(size_t)gi * L.n2 + gj] = Tl[row * TS + col];
+        }
+    }
+    {   // row sums: THREADS / BM lanes per row; column sums: one wave per THREADS / 64-th of the rows (conflict-free
+        // column walks); fixed order throughout
+        constexpr int LPR = T::THREADS / T::BM, CPL = T::BN / LPR;
+        const int row = tid / LPR, hp = tid % LPR;
+        const float* tr = Tl + row * TS + hp * CPL;
         float s = 0.f;
 #pragma unroll 8
-        for (int m = 0; m < 32; ++m) s += tr[m];
-        s += __shfl_xor(s, 1);
+        for (int m = 0; m < CPL; ++m) s += tr[m];
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
         if (hp == 0) rowpart[((size_t)frame * nct + ct) * L.n1p + rt * T::BM + row] = s;
-        const int c = tid & 63, qp = tid >> 6;   // one wave per 32-row quarter: conflict-free column walks
+        constexpr int NQ = T::THREADS / 64, RPQ = T::BM / NQ;
+        const int c = tid & 63, qp = tid >> 6;
         float t = 0.f;
 #pragma unroll 8
-        for (int m = 0; m < 32; ++m) t += Tl[(qp * 32 + m) * TS + c];
+        for (int m = 0; m < RPQ; ++m) t += Tl[(qp * RPQ + m) * TS + c];
         __syncthreads();
-        Tl[qp * 64 + c] = t;   // re-use the tile head for the 4 x 64 quarter sums
+        Tl[qp * 64 + c] = t;   // re-use the tile head for the NQ x 64 part sums
         __syncthreads();
-        if (tid < 64)
-            colpart[((size_t)frame * nrt + rt) * L.n2p + ct * T::BN + tid] = (Tl[tid] + Tl[64 + tid]) + (Tl[128 + tid] + Tl[192 + tid]);
+        if (tid < 64) {
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) tot += Tl[q * 64 + tid];
+            colpart[((size_t)frame * nrt + rt) * L.n2p + ct * T::BN + tid] = tot;
+        }
     }
 }
 
@@ -680,11 +703,18 @@ void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w
                    smem_bytes<FinalTile>(), s, Wf, bf, w.Z, w.MD, w.L);
 }
 
+template <class T>
+static void launch_score_t(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk) {
+    auto kern = score_exp_kernel<T>;
+    GATSSPG_BIG_LDS_ONCE(kern);
+    GATSSPG_LAUNCH(hk, KID_SCORE_EXP, s, kern, dim3(xcd_grid(w.sc_nrt, w.sc_nct), w.L.b), dim3(T::THREADS),
+                   shaped_lds(smem_bytes<T>(), w.sc_nrt * w.sc_nct * w.L.b), s, w.MD, conf, w.rowpart, w.colpart, w.L, scale);
+}
+
 void launch_score_exp(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk) {
-    GATSSPG_BIG_LDS_ONCE(score_exp_kernel);
-    GATSSPG_LAUNCH(hk, KID_SCORE_EXP, s, score_exp_kernel, dim3(xcd_grid(w.sc_nrt, w.sc_nct), w.L.b), dim3(256),
-                   shaped_lds(smem_bytes<ScoreTile>(), w.sc_nrt * w.sc_nct * w.L.b), s, w.MD, conf, w.rowpart, w.colpart,
-                   w.L, scale);
+    static const int ts = env_int("GATSSPG_SCORE_TILE", 1);   // 1 (default): the 128x64 tile on 8 waves (45.2 vs 52.3 us); 0: on 4
+    if (ts == 1) launch_score_t<ScoreTileW8>(w, conf, scale, s, hk);
+    else launch_score_t<ScoreTile>(w, conf, scale, s, hk);
 }
 
 void launch_gats_wlt(const float* W, const float* P, const Workspace& w, int add_h, hipStream_t s, ProfileHook* hk) {
