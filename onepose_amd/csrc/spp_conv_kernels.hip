@@ -391,11 +391,14 @@ static void launch_conv_pool(int gi, int kid, const float* packed, const float* 
         launch_pool(tmp, L, Y2, L2, cout, s, hk);
         return;
     }
-    using T = Tile64x128;
-    auto kern = conv_pool_kernel<T, CIN>;
+    static const bool w8 = getenv("SPP_POOL_TILE") && atoi(getenv("SPP_POOL_TILE")) == 1;   // 1: the 64x128 patch on 8 waves
     const int NT = L.b * (L.H / 2) * ((L.W + 63) / 64);
-    SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(cout / T::BM, NT)), dim3(T::THREADS), smem_bytes<T>(), s,
-               packed + conv_w_off(gi), packed + conv_b_off(gi), X, Y2, L, L2, cout);
+    auto go = [&](auto kern, int threads, size_t lds) {
+        SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(cout / 64, NT)), dim3(threads), lds, s, packed + conv_w_off(gi),
+                   packed + conv_b_off(gi), X, Y2, L, L2, cout);
+    };
+    if (w8) go(conv_pool_kernel<Tile64x128w8, CIN>, Tile64x128w8::THREADS, smem_bytes<Tile64x128w8>());
+    else go(conv_pool_kernel<Tile64x128, CIN>, Tile64x128::THREADS, smem_bytes<Tile64x128>());
 }
 
 void launch_dense(const float* packed, const float* image, const Workspace& w, hipStream_t s, ProfileHook* hk) {
