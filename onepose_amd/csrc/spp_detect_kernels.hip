@@ -46,16 +46,40 @@ __global__ __launch_bounds__(64) void score_map_kernel(const float* __restrict__
 // simple_nms (:47-62), all five max-pools of the two suppression rounds inside one workgroup: a T x T output tile
 // with a 5*R halo (the dependency radius of the final mask) lives in LDS; max-pools are separable.
 // Out-of-image taps are -inf exactly as max_pool2d pads.
+// Each pass gives a thread a strip of 4 consecutive elements along the pooled direction (window values in registers:
+// 4 + 2R LDS reads for 4 outputs) with the 64 lanes of a wave spread along the other direction; row strides of 65
+// floats / 68 bytes make both directions bank-conflict-free.  R is a template parameter so the windows unroll.
 // =====================================================================================================
 constexpr int E = NMS_E;
 constexpr int NMS_THREADS = 1024;
+constexpr int FS = E + 1, BS = E + 4;
 struct NmsSmem {
-    float s[E * E], ss[E * E], t[E * E];
-    unsigned char m[E * E], sup[E * E], tb[E * E];
+    float s[E * FS], ss[E * FS], t[E * FS];
+    unsigned char m[E * BS], sup[E * BS], tb[E * BS];
 };
 
-__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restrict__ score, float* __restrict__ out, int H, int W, int R,
-                                                  int T) {
+// out[p] = op over in[p-R .. p+R] along columns (ALONG_COLS: lane = row, strip walks columns) or rows
+template <int R, int S, bool ALONG_COLS, class V, class Op>
+__device__ __forceinline__ void pool_strip(const V* __restrict__ in, V* __restrict__ out, V ident, Op op) {
+    const int lane = threadIdx.x & 63, p0 = (threadIdx.x >> 6) * 4;
+    V v[4 + 2 * R];
+#pragma unroll
+    for (int j = 0; j < 4 + 2 * R; ++j) {
+        const int p = p0 - R + j;
+        v[j] = (p >= 0 && p < E) ? in[ALONG_COLS ? lane * S + p : p * S + lane] : ident;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        V acc = v[i];
+#pragma unroll
+        for (int d = 1; d <= 2 * R; ++d) acc = op(acc, v[i + d]);
+        out[ALONG_COLS ? lane * S + p0 + i : (p0 + i) * S + lane] = acc;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restrict__ score, float* __restrict__ out, int H, int W,
+                                                          int T) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_raw[];
     NmsSmem& S = *reinterpret_cast<NmsSmem*>(nms_raw);
     const int im = blockIdx.z;
@@ -63,90 +87,68 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
     const float* src = score + (size_t)im * H * W;
     const int tid = threadIdx.x;
     const float NINF = -INFINITY;
-    auto inside = [&](int i) {
-        const int y = y0 + i / E, x = x0 + i % E;
-        return y >= 0 && y < H && x >= 0 && x < W;
-    };
-    for (int i = tid; i < E * E; i += NMS_THREADS) {
-        const int y = y0 + i / E, x = x0 + i % E;
-        S.s[i] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : NINF;
+    auto fmaxop = [](float a, float b) { return fmaxf(a, b); };
+    auto orop = [](unsigned char a, unsigned char b) { return (unsigned char)(a | b); };
+    // element e of the region: row r = e / E, column c = e % E; four per thread
+    bool in_img[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = tid + k * NMS_THREADS, r = e / E, c = e % E;
+        const int y = y0 + r, x = x0 + c;
+        in_img[k] = y >= 0 && y < H && x >= 0 && x < W;
+        S.s[r * FS + c] = in_img[k] ? src[(size_t)y * W + x] : NINF;
     }
     __syncthreads();
-    // separable (2R+1)^2 max over the region (taps outside the region are skipped: they only influence
-    // positions further than the halo from the tile)
-    auto pool_f = [&](const float* in, float* outp) {
-        for (int i = tid; i < E * E; i += NMS_THREADS) {
-            const int r = i / E, c = i % E;
-            float v = NINF;
-            for (int d = -R; d <= R; ++d) {
-                const int cc = c + d;
-                if (cc >= 0 && cc < E) v = fmaxf(v, in[r * E + cc]);
-            }
-            S.t[i] = v;
-        }
-        __syncthreads();
-        for (int i = tid; i < E * E; i += NMS_THREADS) {
-            const int r = i / E, c = i % E;
-            float v = NINF;
-            for (int d = -R; d <= R; ++d) {
-                const int rr = r + d;
-                if (rr >= 0 && rr < E) v = fmaxf(v, S.t[rr * E + c]);
-            }
-            outp[i] = v;
-        }
-        __syncthreads();
-    };
-    auto pool_b = [&](const unsigned char* in, unsigned char* outp) {
-        for (int i = tid; i < E * E; i += NMS_THREADS) {
-            const int r = i / E, c = i % E;
-            unsigned char v = 0;
-            for (int d = -R; d <= R; ++d) {
-                const int cc = c + d;
-                if (cc >= 0 && cc < E) v |= in[r * E + cc];
-            }
-            S.tb[i] = v;
-        }
-        __syncthreads();
-        for (int i = tid; i < E * E; i += NMS_THREADS) {
-            const int r = i / E, c = i % E;
-            unsigned char v = 0;
-            for (int d = -R; d <= R; ++d) {
-                const int rr = r + d;
-                if (rr >= 0 && rr < E) v |= S.tb[rr * E + c];
-            }
-            outp[i] = v;
-        }
-        __syncthreads();
-    };
     // max_mask = scores == max_pool(scores)                                        (:56)
-    pool_f(S.s, S.ss);
-    for (int i = tid; i < E * E; i += NMS_THREADS) S.m[i] = inside(i) && S.s[i] == S.ss[i];
+    pool_strip<R, FS, true>(S.s, S.t, NINF, fmaxop);
+    __syncthreads();
+    pool_strip<R, FS, false>(S.t, S.ss, NINF, fmaxop);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = tid + k * NMS_THREADS, r = e / E, c = e % E;
+        S.m[r * BS + c] = in_img[k] && S.s[r * FS + c] == S.ss[r * FS + c];
+    }
     __syncthreads();
     for (int it = 0; it < 2; ++it) {                                                 // (:57-61)
-        pool_b(S.m, S.sup);                                                           // supp_mask = max_pool(max_mask) > 0
-        for (int i = tid; i < E * E; i += NMS_THREADS) S.ss[i] = inside(i) ? (S.sup[i] ? 0.f : S.s[i]) : NINF;   // supp_scores
+        pool_strip<R, BS, true>(S.m, S.tb, (unsigned char)0, orop);                   // supp_mask = max_pool(max_mask) > 0
         __syncthreads();
-        // new_max_mask = supp_scores == max_pool(supp_scores): pooled values go to a register per element
-        // (the row pass writes S.t, the column pass is consumed immediately)
-        for (int i = tid; i < E * E; i += NMS_THREADS) {
-            const int r = i / E, c = i % E;
-            float v = NINF;
-            for (int d = -R; d <= R; ++d) {
-                const int cc = c + d;
-                if (cc >= 0 && cc < E) v = fmaxf(v, S.ss[r * E + cc]);
-            }
-            S.t[i] = v;
+        pool_strip<R, BS, false>(S.tb, S.sup, (unsigned char)0, orop);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                                 // supp_scores
+            const int e = tid + k * NMS_THREADS, r = e / E, c = e % E;
+            S.ss[r * FS + c] = in_img[k] ? (S.sup[r * BS + c] ? 0.f : S.s[r * FS + c]) : NINF;
         }
         __syncthreads();
-        for (int i = tid; i < E * E; i += NMS_THREADS) {
-            const int r = i / E, c = i % E;
-            float v = NINF;
-            for (int d = -R; d <= R; ++d) {
-                const int rr = r + d;
-                if (rr >= 0 && rr < E) v = fmaxf(v, S.t[rr * E + c]);
+        pool_strip<R, FS, true>(S.ss, S.t, NINF, fmaxop);                             // max_pool(supp_scores): row pass into S.t
+        __syncthreads();
+        // column pass straight into registers: this thread owns the four elements (p0 + i, lane) it produces
+        float colres[4];
+        {
+            const int lane = tid & 63, p0 = (tid >> 6) * 4;
+            float v[4 + 2 * R];
+#pragma unroll
+            for (int j = 0; j < 4 + 2 * R; ++j) {
+                const int p = p0 - R + j;
+                v[j] = (p >= 0 && p < E) ? S.t[p * FS + lane] : NINF;
             }
-            const bool nw = inside(i) && S.ss[i] == v;
-            S.m[i] = S.m[i] | (nw && !S.sup[i]);                                      // max_mask | (new & ~supp)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float acc = v[i];
+#pragma unroll
+                for (int d = 1; d <= 2 * R; ++d) acc = fmaxf(acc, v[i + d]);
+                colres[i] = acc;
+            }
+            // new_max_mask = supp_scores == pooled; max_mask |= new & ~supp          (element (p0+i, lane))
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = p0 + i, c = lane;
+                const int y = y0 + r, x = x0 + c;
+                const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+                const bool nw = inside && S.ss[r * FS + c] == colres[i];
+                S.m[r * BS + c] = S.m[r * BS + c] | (nw && !S.sup[r * BS + c]);
+            }
         }
         __syncthreads();
     }
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restric
         const int ty = i / T, tx = i % T;
         const int y = blockIdx.y * T + ty, x = blockIdx.x * T + tx;
         if (y < H && x < W) {
-            const int j = (ty + 5 * R) * E + tx + 5 * R;
-            dst[(size_t)y * W + x] = S.m[j] ? S.s[j] : 0.f;                            // (:62)
+            const int r = ty + 5 * R, c = tx + 5 * R;
+            dst[(size_t)y * W + x] = S.m[r * BS + c] ? S.s[r * FS + c] : 0.f;         // (:62)
         }
     }
 }
@@ -326,21 +328,23 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
     int* sv = surv + (size_t)im * HW;
     unsigned* sk = skey + (size_t)im * HW;
     int* rk = rank + (size_t)im * HW;
-    int ties_before = 0, out_before = 0;
+    // one scan per 1024-candidate chunk: (score > T) in the low half-word, (score == T) in the high one; a tie is kept
+    // iff fewer than `quota` ties precede it, so its slot is  #greater before + min(#ties before, quota)
+    int gt_before = 0, ties_before = 0;
     for (int i0 = 0; i0 < n; i0 += 1024) {
         const int i = i0 + tid;
         const unsigned k = i < n ? key[i] : 0u;
-        const int tie = i < n && k == T;
-        int tot_t, tot_o;
-        const int tpos = ties_before + block_excl_scan(tie, wsum, tot_t);
-        const int keep = i < n && (k > T || (tie && tpos < quota));
-        const int opos = out_before + block_excl_scan(keep, wsum, tot_o);
-        if (keep) {
+        const int gt = i < n && k > T, tie = i < n && k == T;
+        int tot;
+        const int pre = block_excl_scan(gt | (tie << 16), wsum, tot);
+        const int g = gt_before + (pre & 0xFFFF), t = ties_before + (pre >> 16);
+        if (gt || (tie && t < quota)) {
+            const int opos = g + min(t, quota);
             sv[opos] = c[i];
             sk[opos] = k;
         }
-        ties_before += tot_t;
-        out_before += tot_o;
+        gt_before += tot & 0xFFFF;
+        ties_before += tot >> 16;
     }
     for (int i = tid; i < max_kp; i += 1024) rk[i] = 0;      // accumulators of rank_kernel
 }
@@ -503,17 +507,27 @@ void launch_detect(const float* score_map, DescView dv, const Workspace& w, cons
     if (R == 0) {
         (void)hipMemcpyAsync(nms, score_map, sizeof(float) * (size_t)b * H * W, hipMemcpyDeviceToDevice, s);   // :62 with an all-true mask
     } else {
-        static bool attr_done[16] = {};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev < 16 && !attr_done[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)sizeof(NmsSmem));
-            attr_done[dev] = true;
-        }
         const int T = E - 10 * R < 32 ? E - 10 * R : 32;
-        SPP_LAUNCH(hk, KID_NMS, s, nms_kernel, dim3((W + T - 1) / T, (H + T - 1) / T, b), dim3(NMS_THREADS), sizeof(NmsSmem), s,
-                   score_map, nms, H, W, R, T);
+        const dim3 grid((W + T - 1) / T, (H + T - 1) / T, b);
+        auto go = [&](auto kern) {
+            static bool attr_done[16] = {};            // one flag set per instantiation (this lambda is instantiated per radius)
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev < 16 && !attr_done[dev]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)sizeof(NmsSmem));
+                attr_done[dev] = true;
+            }
+            SPP_LAUNCH(hk, KID_NMS, s, kern, grid, dim3(NMS_THREADS), sizeof(NmsSmem), s, score_map, nms, H, W, T);
+        };
+        switch (R) {
+            case 1: go(nms_kernel<1>); break;
+            case 2: go(nms_kernel<2>); break;
+            case 3: go(nms_kernel<3>); break;
+            case 4: go(nms_kernel<4>); break;
+            case 5: go(nms_kernel<5>); break;
+            default: go(nms_kernel<6>); break;
+        }
     }
     SPP_LAUNCH(hk, KID_ROWCOUNT, s, rowcount_kernel, dim3(H, b), dim3(64), 0, s, nms, H, W, dp.threshold, dp.remove_borders,
                w.rowcnt);
