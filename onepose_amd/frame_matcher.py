@@ -1,0 +1,40 @@
+"""The per-frame part of the reference inference loop (inference.py:132-152) with every hand-off in HBM.
+
+    extractor(image) -> pack_data -> matcher(inp_data) -> valid matches -> (mkpts2d, mkpts3d, mconf)
+
+The reference moves the detector output to the host and back (``.cpu().numpy()`` at :141, ``torch.Tensor(..).cuda()`` in
+``pack_data`` :80-94) and re-uploads the 3D database every frame; here the database dict (``database_io.load_object_database``)
+stays resident, the descriptors go from the extractor's output buffer straight into the matcher, and only the final
+variable-length correspondence lists are gathered (the inputs of ``ransac_PnP``, :155 -- PnP itself is OpenCV on the CPU in
+the reference and is not part of this package).
+"""
+from __future__ import annotations
+
+import torch
+
+
+class FrameMatcher:
+    """extractor: onepose_amd.SuperPoint; matcher: onepose_amd.GATsSuperGlue; database: the dict of
+    ``load_object_database`` (keypoints3d [1,N,3], descriptors3d_db [1,256,N], descriptors2d_db [1,256,N*L])."""
+
+    def __init__(self, extractor, matcher, database, cache_database=True):
+        self.extractor, self.matcher, self.db = extractor, matcher, database
+        for k in ("keypoints3d", "descriptors3d_db", "descriptors2d_db"):
+            if not database[k].is_cuda:
+                raise RuntimeError(f"database['{k}'] must live on the GPU (there is no CPU fallback)")
+        # the query-independent part of the first three GNN layers, computed once per object
+        self.db_cache = matcher.prepare_database(database) if cache_database else None
+
+    @torch.no_grad()
+    def __call__(self, image):
+        """image [1,1,H,W] on the GPU -> dict(mkpts2d [m,2], mkpts3d [m,3], mconf [m], keypoints2d, matches0) (inference.py:140-152)."""
+        det = self.extractor(image)                                           # :140
+        kpts2d, desc2d = det["keypoints"][0], det["descriptors"][0]
+        inp = {"keypoints2d": kpts2d[None], "keypoints3d": self.db["keypoints3d"],            # pack_data :80-94
+               "descriptors2d_query": desc2d[None].contiguous(), "descriptors3d_db": self.db["descriptors3d_db"],
+               "descriptors2d_db": self.db["descriptors2d_db"]}
+        pred, _ = self.matcher(inp, database=self.db_cache) if self.db_cache is not None else self.matcher(inp)   # :146
+        matches, conf = pred["matches0"], pred["matching_scores0"]           # :147-151
+        valid = matches > -1
+        return {"mkpts2d": kpts2d[valid], "mkpts3d": self.db["keypoints3d"][0][matches[valid]], "mconf": conf[valid],
+                "keypoints2d": kpts2d, "matches0": matches}

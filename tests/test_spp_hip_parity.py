@@ -294,3 +294,34 @@ def test_forward_is_capturable_in_a_hip_graph():
     assert n == int(captured[3][0, 0]) == 300
     assert torch.equal(captured[0][0, :n], fresh[0][0, :n]) and torch.equal(captured[2][0, :, :n], fresh[2][0, :, :n])
     assert not torch.equal(captured[0][0, :n], eager[0][0, :n])      # the replay really saw the new image
+
+
+def test_frame_matcher_vs_oracle_chain():
+    """inference.py:140-152 on the GPU (FrameMatcher) against the two oracles chained on the CPU."""
+    from onepose_amd import GATsSuperGlue
+    from onepose_amd.frame_matcher import FrameMatcher
+    from oracle import gatsspg_oracle as mo
+    cfg = {"nms_radius": 3, "max_keypoints": -1}
+    ext, ssd = make_module(5, cfg)
+    hp = dict(mo.DEFAULT_HPARAMS, match_threshold=0.0)
+    msd = synthetic.make_state_dict(1)
+    matcher = GATsSuperGlue(hp)
+    matcher.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in msd.items()}, strict=True)
+    matcher = matcher.cuda().eval()
+    dbn = synthetic.make_inputs(b=1, n1=4, n2=600, num_leaf=8, seed=3)
+    db = {k: torch.from_numpy(dbn[k]).cuda() for k in ("keypoints3d", "descriptors3d_db", "descriptors2d_db")}
+    img = synthetic.make_image(1, 160, 160, 21)
+    ref_det = so.forward(ssd, img, cfg)
+    data = dict(dbn, keypoints2d=ref_det["keypoints"][0][None], descriptors2d_query=ref_det["descriptors"][0][None])
+    ref_pred, _ = mo.forward(msd, data, hp)
+    for cache in (True, False):
+        out = FrameMatcher(ext, matcher, db, cache_database=cache)(torch.from_numpy(img).cuda())
+        np.testing.assert_array_equal(out["keypoints2d"].cpu().numpy(), ref_det["keypoints"][0])
+        m = out["matches0"].cpu().numpy()
+        same = m == ref_pred["matches0"]
+        assert same.mean() > 0.99, same.mean()       # descriptors differ by ~1e-7: a near-tie may resolve differently
+        valid = (m > -1) & same
+        assert valid.sum() > 10
+        np.testing.assert_array_equal(out["mkpts3d"].cpu().numpy(), dbn["keypoints3d"][0][m[m > -1]])
+        np.testing.assert_array_equal(out["mkpts2d"].cpu().numpy(), ref_det["keypoints"][0][m > -1])
+        np.testing.assert_allclose(out["mconf"].cpu().numpy()[same[m > -1]], ref_pred["matching_scores0"][valid], atol=1e-4)
