@@ -1,4 +1,4 @@
-"""Build libgatsspg_hip.so (matcher) and libspp_hip.so (SuperPoint extractor) in-tree with hipcc for gfx950
+"""Build libgatsspg_hip.so (matcher), libspp_hip.so (SuperPoint extractor) and libpnp_hip.so (RANSAC-EPnP) in-tree with hipcc for gfx950
 (cross-compiles without a GPU).
 
     python -m onepose_amd.build_ext [--force] [--remarks] [--profiling]
@@ -18,6 +18,9 @@ HEADERS = ["gatsspg_common.h", "gatsspg_launch.h", "gemm_f32_mfma.h", os.path.jo
 SPP_LIB_PATH = os.path.join(LIB_DIR, "libspp_hip.so")
 SPP_SOURCES = ["spp_conv_kernels.hip", "spp_detect_kernels.hip", "spp_capi.hip"]
 SPP_HEADERS = ["spp_common.h", "gemm_f32_mfma.h", "gatsspg_common.h", os.path.join("..", "..", "include", "superpoint.h")]
+PNP_LIB_PATH = os.path.join(LIB_DIR, "libpnp_hip.so")
+PNP_SOURCES = ["pnp_kernels.hip"]
+PNP_HEADERS = [os.path.join("..", "..", "include", "pnp.h")]
 
 
 def _hipcc():
@@ -35,7 +38,8 @@ def _stale(lib, deps):
 
 
 def is_stale():
-    return _stale(LIB_PATH, SOURCES + HEADERS) or _stale(SPP_LIB_PATH, SPP_SOURCES + SPP_HEADERS)
+    return (_stale(LIB_PATH, SOURCES + HEADERS) or _stale(SPP_LIB_PATH, SPP_SOURCES + SPP_HEADERS)
+            or _stale(PNP_LIB_PATH, PNP_SOURCES + PNP_HEADERS))
 
 
 def build(force=False, remarks=False, verbose=True, profiling=False):
@@ -43,7 +47,8 @@ def build(force=False, remarks=False, verbose=True, profiling=False):
     profiling=True adds -DGATSSPG_PROFILING_BUILD (timing-only ablation variants + the mlp0 timeline hook used by
     tools/trace_mlp0.py); never ship that build."""
     os.makedirs(LIB_DIR, exist_ok=True)
-    for lib, srcs, deps in ((LIB_PATH, SOURCES, SOURCES + HEADERS), (SPP_LIB_PATH, SPP_SOURCES, SPP_SOURCES + SPP_HEADERS)):
+    for lib, srcs, deps in ((LIB_PATH, SOURCES, SOURCES + HEADERS), (SPP_LIB_PATH, SPP_SOURCES, SPP_SOURCES + SPP_HEADERS),
+                            (PNP_LIB_PATH, PNP_SOURCES, PNP_SOURCES + PNP_HEADERS)):
         if not force and not profiling and not _stale(lib, deps):
             continue
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", lib]

@@ -158,3 +158,27 @@ def make_image(b=1, h=512, w=512, seed=0):
         img = img + rs.standard_normal((h, w)) * 0.02
         out[i, 0] = np.clip(img, 0, 1)
     return out
+
+
+# ---- PnP (src/utils/eval_utils.py:18-42) ------------------------------------------------------------------
+def make_pnp_problem(n=300, outlier_frac=0.3, noise_px=0.5, seed=0):
+    """A synthetic 2D-3D correspondence set like the matcher's output: object points in a ~20 cm box (metres, as in
+    the OnePose annotations), a random pose 0.4-0.8 m in front of a 512x512 crop camera, Gaussian pixel noise and a
+    fraction of gross outliers.  -> dict(K [3,3], pts_3d [n,3], pts_2d [n,2], pose_gt [3,4], inlier_mask [n])."""
+    rs = np.random.RandomState(seed)
+    k = np.array([[600.0 + rs.uniform(-50, 50), 0, 256.0 + rs.uniform(-20, 20)],
+                  [0, 600.0 + rs.uniform(-50, 50), 256.0 + rs.uniform(-20, 20)], [0, 0, 1.0]])
+    pts = rs.uniform(-0.1, 0.1, size=(n, 3))
+    a = rs.standard_normal((3, 3))
+    q, r = np.linalg.qr(a)
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    t = np.array([rs.uniform(-0.05, 0.05), rs.uniform(-0.05, 0.05), rs.uniform(0.4, 0.8)])
+    pc = pts @ q.T + t
+    uv = np.stack([k[0, 2] + k[0, 0] * pc[:, 0] / pc[:, 2], k[1, 2] + k[1, 1] * pc[:, 1] / pc[:, 2]], axis=1)
+    uv = uv + rs.standard_normal(uv.shape) * noise_px
+    out = rs.rand(n) < outlier_frac
+    uv[out] = rs.uniform(0, 512, size=(int(out.sum()), 2))
+    return {"K": k, "pts_3d": pts.astype(np.float32), "pts_2d": uv.astype(np.float32),
+            "pose_gt": np.concatenate([q, t[:, None]], axis=1), "inlier_mask": ~out}
