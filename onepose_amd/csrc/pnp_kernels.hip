@@ -50,11 +50,18 @@ __device__ void sample_indices(unsigned long long seed, int hyp, int n, int (&id
 // live in registers.  (A first version with run-time indices kept them in scratch memory and one 5-point EPnP took
 // 10 ms of serial scratch latency.)
 
-// cyclic Jacobi for a symmetric N x N matrix (full storage, kept symmetric): on exit diag(A) = eigenvalues, columns of
-// V = eigenvectors.  The (p, q) sweep is fully unrolled; the sweep loop is rolled and stops when the off-diagonal mass
-// is below 1e-30 of the diagonal mass.
+// index of element (i, j) of a symmetric N x N matrix stored as its upper triangle, row by row
 template <int N>
-__device__ __forceinline__ void jacobi_eig(double (&A)[N][N], double (&V)[N][N], int max_sweeps) {
+__host__ __device__ constexpr int tri(int i, int j) {
+    return i <= j ? i * N - i * (i - 1) / 2 + (j - i) : j * N - j * (j - 1) / 2 + (i - j);
+}
+
+// cyclic Jacobi for a symmetric N x N matrix held as its packed upper triangle S (N (N + 1) / 2 doubles: together with
+// the N x N eigenvector matrix that is 444 registers for N = 12 instead of 576): on exit S[tri(i, i)] = eigenvalues,
+// columns of V = eigenvectors.  The (p, q) sweep is fully unrolled; the sweep loop is rolled and stops when the
+// off-diagonal mass is below 1e-30 of the diagonal mass.
+template <int N>
+__device__ __forceinline__ void jacobi_eig(double (&S)[N * (N + 1) / 2], double (&V)[N][N], int max_sweeps) {
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -63,36 +70,34 @@ __device__ __forceinline__ void jacobi_eig(double (&A)[N][N], double (&V)[N][N],
         double off = 0.0, diag = 0.0;
 #pragma unroll
         for (int p = 0; p < N; ++p) {
-            diag += A[p][p] * A[p][p];
+            diag += S[tri<N>(p, p)] * S[tri<N>(p, p)];
 #pragma unroll
-            for (int q = p + 1; q < N; ++q) off += A[p][q] * A[p][q];
+            for (int q = p + 1; q < N; ++q) off += S[tri<N>(p, q)] * S[tri<N>(p, q)];
         }
         if (!(off > 1e-30 * diag)) break;
 #pragma unroll
         for (int p = 0; p < N - 1; ++p)
 #pragma unroll
             for (int q = p + 1; q < N; ++q) {
-                const double apq = A[p][q];
+                const double apq = S[tri<N>(p, q)];
                 if (apq != 0.0) {
-                    const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                    const double theta = (S[tri<N>(q, q)] - S[tri<N>(p, p)]) / (2.0 * apq);
                     const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                     const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
 #pragma unroll
                     for (int k = 0; k < N; ++k) {
                         if (k != p && k != q) {
-                            const double akp = A[k][p], akq = A[k][q];
-                            const double np_ = c * akp - s * akq, nq_ = s * akp + c * akq;
-                            A[k][p] = np_; A[p][k] = np_;
-                            A[k][q] = nq_; A[q][k] = nq_;
+                            const double akp = S[tri<N>(k, p)], akq = S[tri<N>(k, q)];
+                            S[tri<N>(k, p)] = c * akp - s * akq;
+                            S[tri<N>(k, q)] = s * akp + c * akq;
                         }
                         const double vkp = V[k][p], vkq = V[k][q];
                         V[k][p] = c * vkp - s * vkq;
                         V[k][q] = s * vkp + c * vkq;
                     }
-                    A[p][p] -= t * apq;
-                    A[q][q] += t * apq;
-                    A[p][q] = 0.0;
-                    A[q][p] = 0.0;
+                    S[tri<N>(p, p)] -= t * apq;
+                    S[tri<N>(q, q)] += t * apq;
+                    S[tri<N>(p, q)] = 0.0;
                 }
             }
     }
@@ -143,7 +148,7 @@ __device__ __forceinline__ void lstsq6(double (&A)[6][NC], double (&b)[6], doubl
 }
 
 // eigen-decomposition of a symmetric 3x3 with the eigenpairs sorted by DESCENDING eigenvalue: w[k], columns E[.][k]
-__device__ __forceinline__ void eig3_desc(double (&S)[3][3], double (&w)[3], double (&E)[3][3]) {
+__device__ __forceinline__ void eig3_desc(double (&S)[6], double (&w)[3], double (&E)[3][3]) {
     double V[3][3];
     jacobi_eig<3>(S, V, 16);
 #pragma unroll
@@ -156,11 +161,12 @@ __device__ __forceinline__ void eig3_desc(double (&S)[3][3], double (&w)[3], dou
     for (int c = 0; c < 3; ++c) {
         int rank = 0;                           // number of eigenvalues ordered before column c (ties: lower index first)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) rank += (S[j][j] > S[c][c]) || (S[j][j] == S[c][c] && j < c);
+        for (int j = 0; j < 3; ++j)
+            rank += (S[tri<3>(j, j)] > S[tri<3>(c, c)]) || (S[tri<3>(j, j)] == S[tri<3>(c, c)] && j < c);
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             if (rank == k) {
-                w[k] = S[c][c];
+                w[k] = S[tri<3>(c, c)];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) E[i][k] = V[i][c];
             }
@@ -169,11 +175,11 @@ __device__ __forceinline__ void eig3_desc(double (&S)[3][3], double (&w)[3], dou
 
 // R = U V^T of the SVD of a 3x3 matrix (absolute orientation), reflection fixed as epnp.cpp does (third row negated)
 __device__ __forceinline__ void procrustes_rotation(const double (&M)[3][3], double (&R)[3][3]) {
-    double B[3][3], w[3], Vs[3][3], U[3][3];
+    double B[6], w[3], Vs[3][3], U[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) B[i][j] = M[0][i] * M[0][j] + M[1][i] * M[1][j] + M[2][i] * M[2][j];   // M^T M
+        for (int j = i; j < 3; ++j) B[tri<3>(i, j)] = M[0][i] * M[0][j] + M[1][i] * M[1][j] + M[2][i] * M[2][j];   // M^T M
     eig3_desc(B, w, Vs);
     const double s0 = sqrt(fmax(w[0], 0.0));
 #pragma unroll
@@ -238,7 +244,7 @@ __device__ __forceinline__ bool epnp_solve(int n_rt, Get get, const Cam& cam, do
     });
 #pragma unroll
     for (int k = 0; k < 3; ++k) c0[k] = red(c0[k]) / n;
-    double cov[3][3] = {};
+    double cov[6] = {};
     for_points([&](int i) {
         double pw[3], uv[2];
         get(i, pw, uv);
@@ -246,15 +252,10 @@ __device__ __forceinline__ bool epnp_solve(int n_rt, Get get, const Cam& cam, do
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = a; b < 3; ++b) cov[a][b] += d[a] * d[b];
+            for (int b = a; b < 3; ++b) cov[tri<3>(a, b)] += d[a] * d[b];
     });
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = a; b < 3; ++b) {
-            const double v = red(cov[a][b]);
-            cov[a][b] = v; cov[b][a] = v;
-        }
+    for (int k = 0; k < 6; ++k) cov[k] = red(cov[k]);
     double w3[3], EV[3][3];
     eig3_desc(cov, w3, EV);
     double cws[4][3];
@@ -290,7 +291,7 @@ __device__ __forceinline__ bool epnp_solve(int n_rt, Get get, const Cam& cam, do
         a[0] = 1.0 - a[1] - a[2] - a[3];
     };
     // M^T M (fill_M), mean alphas, G_j = sum_i alpha_ij (pw_i - pw0)
-    double A[12][12] = {};
+    double A[78] = {};                      // M^T M, packed upper triangle
     double abar[4] = {0, 0, 0, 0}, G[4][3] = {};
     for_points([&](int i) {
         double pw[3], uv[2], a[4];
@@ -308,15 +309,10 @@ __device__ __forceinline__ bool epnp_solve(int n_rt, Get get, const Cam& cam, do
 #pragma unroll
         for (int p = 0; p < 12; ++p)
 #pragma unroll
-            for (int q = p; q < 12; ++q) A[p][q] += r1[p] * r1[q] + r2[p] * r2[q];
+            for (int q = p; q < 12; ++q) A[tri<12>(p, q)] += r1[p] * r1[q] + r2[p] * r2[q];
     });
 #pragma unroll
-    for (int p = 0; p < 12; ++p)
-#pragma unroll
-        for (int q = p; q < 12; ++q) {
-            const double v = red(A[p][q]);
-            A[p][q] = v; A[q][p] = v;
-        }
+    for (int k = 0; k < 78; ++k) A[k] = red(A[k]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         abar[j] = red(abar[j]) / n;
@@ -342,7 +338,8 @@ __device__ __forceinline__ bool epnp_solve(int n_rt, Get get, const Cam& cam, do
         for (int c = 0; c < 12; ++c) {
             int rank = 0;                       // eigenvalues ordered before column c (ascending, ties: lower index first)
 #pragma unroll
-            for (int j = 0; j < 12; ++j) rank += (A[j][j] < A[c][c]) || (A[j][j] == A[c][c] && j < c);
+            for (int j = 0; j < 12; ++j)
+                rank += (A[tri<12>(j, j)] < A[tri<12>(c, c)]) || (A[tri<12>(j, j)] == A[tri<12>(c, c)] && j < c);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 if (rank == s) {
