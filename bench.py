@@ -23,6 +23,7 @@ The JSON line also carries
                                         (same JSON contract, metric extractor_images_per_sec; never the headline value)
     python bench.py --pipeline [...]    image -> extractor -> matcher with nothing leaving HBM (inference.py:140-146 without
                                         the GPU->CPU->GPU round trip of pack_data); informative
+    python bench.py --pnp [...]         RANSAC-EPnP pose from 500 synthetic correspondences, 10000 hypotheses
     python bench.py [--extractor] --torch-eager   the same ALGORITHM through stock PyTorch-ROCm ops on this GPU (the
                                         oracle/torch_* restatements: one ATen / rocBLAS / MIOpen launch per op, like the
                                         reference modules) -- an informative baseline line, no HIP kernels of this repo
@@ -411,6 +412,53 @@ def main_pipeline(args):
                                  "single_frame_latency_ms": round(lat * 1e3, 4)}}), flush=True)
 
 
+def main_pnp(args):
+    """RANSAC-EPnP (eval_utils.ransac_PnP, :18-42): 500 correspondences, 40 % outliers, 0.5 px noise, 10000 hypotheses."""
+    from onepose_amd import _native_pnp, pnp
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    n, iters = 500, pnp.ITERATIONS
+    prob = synthetic.make_pnp_problem(n, 0.4, 0.5, 8)
+    p2, p3 = torch.from_numpy(prob["pts_2d"]).to(device), torch.from_numpy(prob["pts_3d"]).to(device)
+    lib = _native_pnp.load()
+    kk = pnp._k_array(prob["K"])
+    ws = torch.empty(lib.pnp_workspace_bytes(n, iters), device=device, dtype=torch.uint8)
+    pose = torch.empty(3, 4, device=device, dtype=torch.float64)
+    mask = torch.zeros(n, device=device, dtype=torch.int32)
+    info = torch.zeros(4, device=device, dtype=torch.int32)
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    def step(i):
+        _native_pnp.check(lib.pnp_ransac_epnp(p3.data_ptr(), p2.data_ptr(), kk, 1000.0, n, pnp.REPROJ_ERROR, iters, i, pose.data_ptr(),
+                                              mask.data_ptr(), info.data_ptr(), ws.data_ptr(), ws.numel(), stream), "pnp_ransac_epnp")
+
+    K, W = args.steps, args.warmup
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / K
+    r_err, t_err = pnp.query_pose_error(pose.cpu().numpy(), prob["pose_gt"])
+    out = {"metric": "pnp_solves_per_sec", "value": round(1.0 / dt, 2), "unit": "solves/s", "n_gpus": 1, "steps": K, "warmup": W,
+           "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"RANSAC-EPnP, {n} correspondences (40 % outliers, 0.5 px noise), {iters} hypotheses of 5 points, "
+                                  "reprojection threshold 5 px, final EPnP over the inliers",
+                      "inliers": int(info[1]), "rotation_error_deg": round(float(r_err), 4), "translation_error_cm": round(float(t_err), 4)}}
+    if not args.no_cpu_baseline:
+        from oracle import pnp_oracle as po
+        sample = 300
+        t0 = time.perf_counter()
+        po.solve_pnp_ransac(prob["pts_3d"].astype(np.float64) * 1000, prob["pts_2d"], prob["K"], 5.0, sample, 0)
+        cdt = (time.perf_counter() - t0) * iters / sample
+        out["cpu_baseline"] = {"value": round(1.0 / cdt, 4), "unit": "solves/s", "cores": 1, "kind": "port",
+                               "sample": f"{sample} of the {iters} hypotheses (time x {iters / sample:.1f}), numpy fp64 oracle (oracle/pnp_oracle.py); the "
+                                         "reference's cv2.solvePnPRansac is not installed here and stops early at its confidence bound"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -427,7 +475,10 @@ def main():
     ap.add_argument("--pipeline", action="store_true", help="image -> extractor -> matcher, all hand-offs in HBM (informative)")
     ap.add_argument("--torch-eager", action="store_true",
                     help="informative baseline: the reference algorithm through stock PyTorch-ROCm ops on this GPU")
+    ap.add_argument("--pnp", action="store_true", help="benchmark the RANSAC-EPnP pose solver (informative)")
     args = ap.parse_args()
+    if args.pnp:
+        return main_pnp(args)
     if args.torch_eager:
         return main_torch_eager(args)
     if args.pipeline:

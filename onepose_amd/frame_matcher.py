@@ -5,8 +5,8 @@
 The reference moves the detector output to the host and back (``.cpu().numpy()`` at :141, ``torch.Tensor(..).cuda()`` in
 ``pack_data`` :80-94) and re-uploads the 3D database every frame; here the database dict (``database_io.load_object_database``)
 stays resident, the descriptors go from the extractor's output buffer straight into the matcher, and only the final
-variable-length correspondence lists are gathered (the inputs of ``ransac_PnP``, :155 -- PnP itself is OpenCV on the CPU in
-the reference and is not part of this package).
+variable-length correspondence lists are gathered; ``solve_pose`` feeds them, still on the GPU, to the RANSAC-EPnP solver
+of ``onepose_amd.pnp`` (``ransac_PnP``, :155).
 """
 from __future__ import annotations
 
@@ -38,3 +38,11 @@ class FrameMatcher:
         valid = matches > -1
         return {"mkpts2d": kpts2d[valid], "mkpts3d": self.db["keypoints3d"][0][matches[valid]], "mconf": conf[valid],
                 "keypoints2d": kpts2d, "matches0": matches}
+
+    @torch.no_grad()
+    def solve_pose(self, image, K_crop, scale=1000, seed=0):
+        """image -> (pose_pred [3,4], pose_pred_homo [4,4], inliers [m,1]) like inference.py:140-155; numpy outputs, identity
+        when fewer than 5 matches survive or the solve fails (eval_utils.py:40-42)."""
+        from . import pnp
+        out = self(image)
+        return pnp.ransac_PnP(K_crop, out["mkpts2d"], out["mkpts3d"], scale=scale, seed=seed)

@@ -119,3 +119,23 @@ def test_hip_epnp_vs_oracle_and_drop_in_signature():
     assert (~q["inlier_mask"])[inliers[:, 0]].sum() <= 3
     pose, homo, inliers = pnp.ransac_PnP(q["K"], q["pts_2d"][:3], q["pts_3d"][:3])
     assert np.array_equal(pose, np.eye(4)[:3]) and inliers == []
+
+
+@pytest.mark.gpu
+def test_frame_matcher_solve_pose_plumbing():
+    """inference.py:140-155 end to end on the GPU: too few matches -> identity (eval_utils.py:40-42), otherwise a [3,4] pose."""
+    import torch
+    from onepose_amd import FrameMatcher, GATsSuperGlue, SuperPoint
+    ext = SuperPoint({"nms_radius": 3, "max_keypoints": 200})
+    ext.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_spp_state_dict(0).items()}, strict=True)
+    hp = {"descriptor_dim": 256, "keypoints_encoder": [32, 64, 128], "match_type": "softmax", "scale_factor": 0.07,
+          "match_threshold": 0.0, "include_self": True, "additional": False, "with_linear_transform": False}
+    m = GATsSuperGlue(hp)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic.make_state_dict(0).items()}, strict=True)
+    dbn = synthetic.make_inputs(b=1, n1=4, n2=300, num_leaf=8, seed=3)
+    db = {k: torch.from_numpy(dbn[k]).cuda() for k in ("keypoints3d", "descriptors3d_db", "descriptors2d_db")}
+    fm = FrameMatcher(ext.cuda().eval(), m.cuda().eval(), db)
+    K = np.array([[600.0, 0, 128], [0, 600, 128], [0, 0, 1]])
+    pose, homo, inliers = fm.solve_pose(torch.from_numpy(synthetic.make_image(1, 256, 256, 4)).cuda(), K)
+    assert pose.shape == (3, 4) and homo.shape == (4, 4) and np.isfinite(pose).all()
+    np.testing.assert_allclose(homo[3], [0, 0, 0, 1])
