@@ -88,3 +88,34 @@ def query_pose_error(pose_pred, pose_gt):
     trace = np.trace(np.dot(pose_pred[:, :3], pose_gt[:, :3].T))
     trace = trace if trace <= 3 else 3
     return np.rad2deg(np.arccos((trace - 1.0) / 2.0)), translation_distance
+
+
+class Evaluator:
+    """cm-degree pose accuracy over a sequence: host-side mirror of src/evaluators/cmd_evaluator.py (the bookkeeping
+    inference.py:102,163,166 does around the pose solver).  A frame counts for the k cm / k degree metric when its
+    translation error is below k cm AND its rotation error below k degrees (k = 1, 3, 5)."""
+
+    THRESHOLDS = (1, 3, 5)
+
+    def __init__(self):
+        self.cmd1, self.cmd3, self.cmd5, self.cmd7, self.add = [], [], [], [], []
+
+    def _hits(self, k):
+        return {1: self.cmd1, 3: self.cmd3, 5: self.cmd5}[k]
+
+    def evaluate(self, pose_pred, pose_gt):
+        if pose_pred is None:                      # cmd_evaluator.py:36-40 (also feeds the unused 7 cm list)
+            for k in self.THRESHOLDS:
+                self._hits(k).append(False)
+            self.cmd7.append(False)
+            return
+        ang, trans = query_pose_error(pose_pred, pose_gt)
+        for k in self.THRESHOLDS:
+            self._hits(k).append(bool(trans < k and ang < k))
+
+    def summarize(self):
+        out = {f"cmd{k}": np.mean(self._hits(k)) for k in self.THRESHOLDS}
+        for k in self.THRESHOLDS:
+            print(f"{k} cm {k} degree metric: {out[f'cmd{k}']}")
+        self.cmd1, self.cmd3, self.cmd5, self.cmd7 = [], [], [], []
+        return out

@@ -182,3 +182,27 @@ def make_pnp_problem(n=300, outlier_frac=0.3, noise_px=0.5, seed=0):
     uv[out] = rs.uniform(0, 512, size=(int(out.sum()), 2))
     return {"K": k, "pts_3d": pts.astype(np.float32), "pts_2d": uv.astype(np.float32),
             "pose_gt": np.concatenate([q, t[:, None]], axis=1), "inlier_mask": ~out}
+
+
+def make_pose_pairs(seed=0, n=40):
+    """(pose_pred, pose_gt) pairs whose rotation / translation errors straddle the 1, 3 and 5 cm-degree thresholds of the
+    reference evaluator; every 7th prediction is given as a 4x4 matrix (cmd_evaluator.py:42-45)."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        q, _ = np.linalg.qr(rs.standard_normal((3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        t = rs.uniform(-0.3, 0.3, 3) + np.array([0, 0, 0.6])
+        ang = rs.choice([0.2, 0.8, 2.0, 4.0, 8.0]) * np.pi / 180
+        ax = rs.standard_normal(3)
+        ax /= np.linalg.norm(ax)
+        kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        dr = np.eye(3) + np.sin(ang) * kx + (1 - np.cos(ang)) * kx @ kx
+        dt = rs.choice([0.002, 0.008, 0.02, 0.04, 0.08]) * ax
+        gt = np.concatenate([q, t[:, None]], 1)
+        pred = np.concatenate([dr @ q, (t + dt)[:, None]], 1)
+        if i % 7 == 0:
+            pred = np.concatenate([pred, [[0, 0, 0, 1.0]]], 0)
+        out.append((pred, gt))
+    return out

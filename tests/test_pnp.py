@@ -139,3 +139,17 @@ def test_frame_matcher_solve_pose_plumbing():
     pose, homo, inliers = fm.solve_pose(torch.from_numpy(synthetic.make_image(1, 256, 256, 4)).cuda(), K)
     assert pose.shape == (3, 4) and homo.shape == (4, 4) and np.isfinite(pose).all()
     np.testing.assert_allclose(homo[3], [0, 0, 0, 1])
+
+
+def test_evaluator_matches_reference_golden(capsys):
+    """cm-degree bookkeeping against tests/golden/eval_golden.json (made by running the reference Evaluator)."""
+    import json
+    from onepose_amd.pnp import Evaluator
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "eval_golden.json")))
+    ev = Evaluator()
+    for i, (pred, gt) in enumerate(synthetic.make_pose_pairs(g["seed"])):
+        ev.evaluate(None if i == g["none_at"] else pred, gt)
+    assert ev.cmd1 == g["hits"]["cmd1"] and ev.cmd3 == g["hits"]["cmd3"] and ev.cmd5 == g["hits"]["cmd5"]
+    out = ev.summarize()
+    assert {k: float(v) for k, v in out.items()} == g["summary"] and ev.cmd1 == []
+    assert "1 cm 1 degree metric" in capsys.readouterr().out
