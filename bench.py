@@ -106,11 +106,12 @@ class Runner:
         self.s0 = torch.empty(b, n1, device=device)
         self.s1 = torch.empty(b, n2, device=device)
         self.stream = torch.cuda.Stream(device) if own_stream else torch.cuda.current_stream(device)
+        self.match_threshold = HP["match_threshold"]
 
     def _common(self, i):
         q = self.queries[i % len(self.queries)]
         return (self.packed.data_ptr(), q.data_ptr(), self.d3.data_ptr(), self.d2db.data_ptr(), self.b, self.n1, self.n2,
-                NUM_LEAF, self.flags, HP["scale_factor"], HP["match_threshold"], self.conf.data_ptr(), self.m0.data_ptr(),
+                NUM_LEAF, self.flags, HP["scale_factor"], self.match_threshold, self.conf.data_ptr(), self.m0.data_ptr(),
                 self.m1.data_ptr(), self.s0.data_ptr(), self.s1.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
                 self.stream.cuda_stream)
 
@@ -364,9 +365,33 @@ def main_torch_eager(args):
                       "value": round(1 / dt, 2), "unit": unit}), flush=True)
 
 
+class PnpStage:
+    """RANSAC-EPnP straight from one slot's extractor keypoints and matcher matches (pnp_ransac_epnp_matches)."""
+
+    def __init__(self, device, sp, mt):
+        from onepose_amd import _native_pnp, pnp
+        self.lib, self.sp, self.mt = _native_pnp.load(), sp, mt
+        self.iters = pnp.ITERATIONS
+        self.k = pnp._k_array(np.array([[600.0, 0, 256], [0, 600.0, 256], [0, 0, 1]]))
+        self.kp3 = torch.from_numpy(np.random.RandomState(5).uniform(-0.1, 0.1, (mt.n2, 3)).astype(np.float32)).to(device)
+        self.ws = torch.empty(self.lib.pnp_workspace_bytes(mt.n1, self.iters), device=device, dtype=torch.uint8)
+        self.pose = torch.empty(3, 4, device=device, dtype=torch.float64)
+        self.mask = torch.empty(mt.n1, device=device, dtype=torch.int32)
+        self.info = torch.empty(4, device=device, dtype=torch.int32)
+
+    def step(self, i):
+        from onepose_amd import _native_pnp, pnp
+        _native_pnp.check(self.lib.pnp_ransac_epnp_matches(
+            self.sp.kp.data_ptr(), self.kp3.data_ptr(), self.mt.m0.data_ptr(), self.mt.n1, self.k, 1000.0, pnp.REPROJ_ERROR, self.iters, i,
+            self.pose.data_ptr(), self.mask.data_ptr(), self.info.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+            self.mt.stream.cuda_stream), "pnp_ransac_epnp_matches")
+
+
 def main_pipeline(args):
-    """image -> SuperPoint -> GATsSPG on one stream, descriptors handed over inside HBM (no host round trip; the
-    matcher runs on all max_keypoints slots -- the synthetic image fills them)."""
+    """image -> SuperPoint -> GATsSPG -> RANSAC-EPnP on one stream per frame, every hand-off inside HBM (no host round
+    trip: the matcher runs on all max_keypoints slots -- the synthetic image fills them -- and the pose solver selects the
+    valid matches on the device).  Random weights: the matches (threshold 0) are geometrically meaningless, the work is real."""
+    from onepose_amd import _native_pnp, pnp
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
     model = SuperPoint({**SPP_CFG, "max_keypoints": N1})
@@ -382,17 +407,20 @@ def main_pipeline(args):
         mt = Runner(device, weights, base.shared_inputs, own_stream=False)
         mt.stream = sp.stream
         mt.queries = [sp.de]                      # [1, 256, N1] written by the extractor, read by the matcher
-        slots.append((sp, mt))
+        mt.match_threshold = 0.0
+        slots.append((sp, mt, PnpStage(device, sp, mt)))
 
-    def step(i):
-        sp, mt = slots[i % S]
+    def step(i, slot=None):
+        sp, mt, pn = slots[i % S] if slot is None else slot
         sp.step(i)
         mt.step(i)
+        pn.step(i)
 
     for i in range(W):
         step(i)
     torch.cuda.synchronize(device)
     assert int(slots[0][0].cnt[0, 0]) == N1, "the synthetic image must fill all keypoint slots"
+    n_matches = int((slots[0][1].m0[0] > -1).sum())
     t0 = time.perf_counter()
     for i in range(K):
         step(i)
@@ -401,14 +429,14 @@ def main_pipeline(args):
     S1 = slots[:1]
     t0 = time.perf_counter()
     for i in range(K):
-        S1[0][0].step(i)
-        S1[0][1].step(i)
+        step(i, S1[0])
     torch.cuda.synchronize(device)
     lat = (time.perf_counter() - t0) / K
     print(json.dumps({"metric": "pipeline_frames_per_sec", "value": round(thr, 2), "unit": "frames/s", "n_gpus": 1, "steps": K,
                       "warmup": W, "ms_per_step": round(1e3 / thr, 4), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
-                      "config": {"workload": f"{SPP_H}x{SPP_W} crop -> SuperPoint (top {N1}) -> GATsSPG vs N_3D={N2} database, "
-                                             "batch 1, all hand-offs in HBM", "frames_in_flight": S,
+                      "config": {"workload": f"{SPP_H}x{SPP_W} crop -> SuperPoint (top {N1}) -> GATsSPG vs N_3D={N2} database -> RANSAC-EPnP "
+                                             f"({pnp.ITERATIONS} hypotheses), batch 1, all hand-offs in HBM", "frames_in_flight": S,
+                                 "matches_into_pnp": n_matches,
                                  "single_frame_latency_ms": round(lat * 1e3, 4)}}), flush=True)
 
 

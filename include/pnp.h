@@ -43,6 +43,16 @@ int pnp_ransac_epnp(const float* pts_3d, const float* pts_2d, const double* K_ho
                     double reproj_error, int iterations, uint64_t seed, double* pose, int32_t* inlier_mask,
                     int32_t* info, void* workspace, size_t workspace_bytes, pnp_stream_t stream);
 
+/* The same solve straight from the matcher's outputs, with the selection of inference.py:148-152 done on the device
+ * (valid = matches0 > -1; mkpts2d = kpts2d[valid]; mkpts3d = kpts3d[matches0[valid]]) so that the number of
+ * correspondences never has to reach the host:
+ *   kpts2d [n1][2] fp32 (extractor keypoints), kpts3d [N3][3] fp32 (database points), matches0 [n1] int64 (-1 = unmatched);
+ *   inlier_mask [n1] int32 indexed by QUERY KEYPOINT; info as above (ok = 0 and identity pose when fewer than 5 matches).
+ * pnp_workspace_bytes(n1, iterations) sizes the workspace. */
+int pnp_ransac_epnp_matches(const float* kpts2d, const float* kpts3d, const int64_t* matches0, int n1, const double* K_host,
+                            double scale, double reproj_error, int iterations, uint64_t seed, double* pose,
+                            int32_t* inlier_mask, int32_t* info, void* workspace, size_t workspace_bytes, pnp_stream_t stream);
+
 /* EPnP alone over all n >= 4 correspondences (cv2.solvePnP(..., flags=SOLVEPNP_EPNP)); stage tests. */
 int pnp_epnp(const float* pts_3d, const float* pts_2d, const double* K_host, double scale, int n, double* pose,
              void* workspace, size_t workspace_bytes, pnp_stream_t stream);

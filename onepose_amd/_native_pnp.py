@@ -15,6 +15,8 @@ SYMBOLS = {
     "pnp_workspace_bytes": (c_size_t, [c_int, c_int]),
     "pnp_ransac_epnp": (c_int, [c_void_p, c_void_p, POINTER(c_double), c_double, c_int, c_double, c_int, c_uint64, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pnp_ransac_epnp_matches": (c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_double), c_double, c_double, c_int, c_uint64,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pnp_epnp": (c_int, [c_void_p, c_void_p, POINTER(c_double), c_double, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 

@@ -480,10 +480,18 @@ __device__ __forceinline__ bool epnp_solve(int n_rt, Get get, const Cam& cam, do
 }
 
 // ---- kernels --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void hyp_kernel(const float* __restrict__ p3, const float* __restrict__ p2, int n, double scale,
-                                                 Cam cam, unsigned long long seed, int iterations, double* __restrict__ hyp) {
+// n_dev != nullptr: the number of correspondences is only known on the device (gather_matches_kernel)
+__global__ __launch_bounds__(64) void hyp_kernel(const float* __restrict__ p3, const float* __restrict__ p2, int n_host,
+                                                 const int* __restrict__ n_dev, double scale, Cam cam, unsigned long long seed,
+                                                 int iterations, double* __restrict__ hyp) {
     const int h = blockIdx.x * 64 + threadIdx.x;
     if (h >= iterations) return;
+    const int n = n_dev ? *n_dev : n_host;
+    const double nan = __longlong_as_double(0x7FF8000000000000ll);
+    if (n < MODEL_POINTS) {                                  // too few matches: no model (eval_utils.py:40-42)
+        for (int k = 0; k < 12; ++k) hyp[(size_t)h * 12 + k] = nan;
+        return;
+    }
     int idx[MODEL_POINTS];
     sample_indices(seed, h, n, idx);
     double spw[MODEL_POINTS][3], suv[MODEL_POINTS][2];
@@ -499,7 +507,6 @@ __global__ __launch_bounds__(64) void hyp_kernel(const float* __restrict__ p3, c
     double R[3][3], t[3];
     const bool ok = epnp_solve<MODEL_POINTS>(MODEL_POINTS, get, cam, R, t);
     double* o = hyp + (size_t)h * 12;
-    const double nan = __longlong_as_double(0x7FF8000000000000ll);
     for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) o[r * 4 + c] = ok ? R[r][c] : nan;
         o[r * 4 + 3] = ok ? t[r] : nan;
@@ -516,11 +523,12 @@ __device__ __forceinline__ bool is_inlier(const double* __restrict__ P, const fl
     return du * du + dv * dv <= thr2;      // false for NaN poses / points at infinity
 }
 
-__global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ p3, const float* __restrict__ p2, int n, double scale,
-                                                    Cam cam, double thr2, int iterations, const double* __restrict__ hyp,
-                                                    int* __restrict__ counts) {
+__global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ p3, const float* __restrict__ p2, int n_host,
+                                                    const int* __restrict__ n_dev, double scale, Cam cam, double thr2, int iterations,
+                                                    const double* __restrict__ hyp, int* __restrict__ counts) {
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (h >= iterations) return;
+    const int n = n_dev ? *n_dev : n_host;
     double P[12];
     for (int k = 0; k < 12; ++k) P[k] = hyp[(size_t)h * 12 + k];
     int cnt = 0;
@@ -532,12 +540,16 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ p3
     if (lane == 0) counts[h] = cnt;
 }
 
-__global__ __launch_bounds__(1024) void best_kernel(const float* __restrict__ p3, const float* __restrict__ p2, int n, double scale,
-                                                    Cam cam, double thr2, int iterations, const double* __restrict__ hyp,
-                                                    const int* __restrict__ counts, int32_t* __restrict__ mask,
+// src != nullptr: correspondence i came from query keypoint src[i]; the inlier mask is indexed by query keypoint
+// (pre-zeroed by gather_matches_kernel)
+__global__ __launch_bounds__(1024) void best_kernel(const float* __restrict__ p3, const float* __restrict__ p2, int n_host,
+                                                    const int* __restrict__ n_dev, double scale, Cam cam, double thr2, int iterations,
+                                                    const double* __restrict__ hyp, const int* __restrict__ counts,
+                                                    const int* __restrict__ src, int32_t* __restrict__ mask,
                                                     int* __restrict__ inl_idx, int32_t* __restrict__ info) {
     __shared__ int sc[1024], si[1024], wsum[16];
     const int tid = threadIdx.x;
+    const int n = n_dev ? *n_dev : n_host;
     int bc = -1, bi = 0x7FFFFFFF;
     for (int h = tid; h < iterations; h += 1024) {
         const int c = counts[h];
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(1024) void best_kernel(const float* __restrict__ p3
     for (int i0 = 0; i0 < n; i0 += 1024) {                 // inlier mask + ordered index list
         const int i = i0 + tid;
         const int in = ok && i < n && is_inlier(P, p3, p2, i, scale, cam, thr2);
-        if (i < n) mask[i] = in;
+        if (i < n) mask[src ? src[i] : i] = in;
         const int lane = tid & 63, wave = tid >> 6;
         int inc = in;
         for (int d = 1; d < 64; d <<= 1) {
@@ -580,6 +592,45 @@ __global__ __launch_bounds__(1024) void best_kernel(const float* __restrict__ p3
     if (tid == 0) {
         info[0] = ok; info[1] = ok ? run : 0; info[2] = ok ? best : -1; info[3] = bcount < 0 ? 0 : bcount;
     }
+}
+
+// inference.py:148-152 on the device: valid = matches0 > -1; mkpts2d = kpts2d[valid]; mkpts3d = kpts3d[matches0[valid]] --
+// ordered compaction by one workgroup; also zeroes the per-keypoint inlier mask
+__global__ __launch_bounds__(1024) void gather_matches_kernel(const float* __restrict__ kpts2d, const float* __restrict__ kpts3d,
+                                                              const long long* __restrict__ matches0, int n1, float* __restrict__ p2,
+                                                              float* __restrict__ p3, int* __restrict__ src, int* __restrict__ count,
+                                                              int32_t* __restrict__ mask) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int run = 0;
+    for (int i0 = 0; i0 < n1; i0 += 1024) {
+        const int i = i0 + tid;
+        const long long m = i < n1 ? matches0[i] : -1;
+        const int valid = m > -1;
+        if (i < n1) mask[i] = 0;
+        int inc = valid;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) base += wsum[w];
+            tot += wsum[w];
+        }
+        if (valid) {
+            const int o = run + base + inc - 1;
+            p2[(size_t)o * 2] = kpts2d[(size_t)i * 2];
+            p2[(size_t)o * 2 + 1] = kpts2d[(size_t)i * 2 + 1];
+            for (int c = 0; c < 3; ++c) p3[(size_t)o * 3 + c] = kpts3d[(size_t)m * 3 + c];
+            src[o] = i;
+        }
+        run += tot;
+    }
+    if (tid == 0) *count = run;
 }
 
 // EPnP over the listed correspondences (idx == nullptr: all n); info != nullptr: RANSAC refit (count from info[1])
@@ -616,7 +667,8 @@ __global__ __launch_bounds__(64) void refit_kernel(const float* __restrict__ p3,
 
 struct Workspace {
     double* hyp;
-    int *counts, *inl;
+    int *counts, *inl, *src, *count;
+    float *p2, *p3;
     size_t bytes;
 };
 inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
@@ -628,6 +680,10 @@ inline Workspace carve(void* base, int n, int iterations) {
     w.hyp = (double*)take(sizeof(double) * 12 * (size_t)iterations);
     w.counts = (int*)take(sizeof(int) * (size_t)iterations);
     w.inl = (int*)take(sizeof(int) * (size_t)n);
+    w.src = (int*)take(sizeof(int) * (size_t)n);
+    w.count = (int*)take(sizeof(int));
+    w.p2 = (float*)take(sizeof(float) * 2 * (size_t)n);
+    w.p3 = (float*)take(sizeof(float) * 3 * (size_t)n);
     w.bytes = off;
     return w;
 }
@@ -676,14 +732,39 @@ int pnp_ransac_epnp(const float* pts_3d, const float* pts_2d, const double* K_ho
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const Cam cam = cam_of(K_host);
     const double thr2 = reproj_error * reproj_error;
-    hipLaunchKernelGGL(hyp_kernel, dim3((iterations + 63) / 64), dim3(64), 0, s, pts_3d, pts_2d, n, scale, cam,
+    const int* nd = nullptr;
+    hipLaunchKernelGGL(hyp_kernel, dim3((iterations + 63) / 64), dim3(64), 0, s, pts_3d, pts_2d, n, nd, scale, cam,
                        (unsigned long long)seed, iterations, w.hyp);
-    hipLaunchKernelGGL(score_kernel, dim3((iterations + 3) / 4), dim3(256), 0, s, pts_3d, pts_2d, n, scale, cam, thr2, iterations,
-                       w.hyp, w.counts);
-    hipLaunchKernelGGL(best_kernel, dim3(1), dim3(1024), 0, s, pts_3d, pts_2d, n, scale, cam, thr2, iterations, w.hyp, w.counts,
-                       inlier_mask, w.inl, info);
+    hipLaunchKernelGGL(score_kernel, dim3((iterations + 3) / 4), dim3(256), 0, s, pts_3d, pts_2d, n, nd, scale, cam, thr2,
+                       iterations, w.hyp, w.counts);
+    hipLaunchKernelGGL(best_kernel, dim3(1), dim3(1024), 0, s, pts_3d, pts_2d, n, nd, scale, cam, thr2, iterations, w.hyp, w.counts,
+                       nd, inlier_mask, w.inl, info);
     hipLaunchKernelGGL(refit_kernel, dim3(1), dim3(64), 0, s, pts_3d, pts_2d, n, scale, cam, w.inl, info, pose);
     return check_launch("pnp_ransac_epnp");
+}
+
+int pnp_ransac_epnp_matches(const float* kpts2d, const float* kpts3d, const int64_t* matches0, int n1, const double* K_host,
+                            double scale, double reproj_error, int iterations, uint64_t seed, double* pose, int32_t* inlier_mask,
+                            int32_t* info, void* workspace, size_t workspace_bytes, pnp_stream_t stream) {
+    if (!kpts2d || !kpts3d || !matches0 || !K_host || !pose || !inlier_mask || !info || !workspace) return fail("null argument");
+    if (n1 < 1) return fail("n1 must be >= 1");
+    if (iterations < 1 || iterations > (1 << 24)) return fail("iterations out of range");
+    if (!(scale > 0.0) || !(reproj_error > 0.0)) return fail("scale and reproj_error must be positive");
+    Workspace w = carve(workspace, n1, iterations);
+    if (workspace_bytes < w.bytes) return fail("workspace too small: %zu < %zu bytes", workspace_bytes, w.bytes);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const Cam cam = cam_of(K_host);
+    const double thr2 = reproj_error * reproj_error;
+    hipLaunchKernelGGL(gather_matches_kernel, dim3(1), dim3(1024), 0, s, kpts2d, kpts3d, reinterpret_cast<const long long*>(matches0),
+                       n1, w.p2, w.p3, w.src, w.count, inlier_mask);
+    hipLaunchKernelGGL(hyp_kernel, dim3((iterations + 63) / 64), dim3(64), 0, s, w.p3, w.p2, 0, w.count, scale, cam,
+                       (unsigned long long)seed, iterations, w.hyp);
+    hipLaunchKernelGGL(score_kernel, dim3((iterations + 3) / 4), dim3(256), 0, s, w.p3, w.p2, 0, w.count, scale, cam, thr2, iterations,
+                       w.hyp, w.counts);
+    hipLaunchKernelGGL(best_kernel, dim3(1), dim3(1024), 0, s, w.p3, w.p2, 0, w.count, scale, cam, thr2, iterations, w.hyp, w.counts,
+                       w.src, inlier_mask, w.inl, info);
+    hipLaunchKernelGGL(refit_kernel, dim3(1), dim3(64), 0, s, w.p3, w.p2, 0, scale, cam, w.inl, info, pose);
+    return check_launch("pnp_ransac_epnp_matches");
 }
 
 int pnp_epnp(const float* pts_3d, const float* pts_2d, const double* K_host, double scale, int n, double* pose, void* workspace,

@@ -40,6 +40,20 @@ class FrameMatcher:
                 "keypoints2d": kpts2d, "matches0": matches}
 
     @torch.no_grad()
+    def solve_pose_device(self, image, K_crop, scale=1000, seed=0):
+        """image -> (pose [3,4] float64, inlier mask per query keypoint, info [4], detections) all left on the GPU: the valid
+        matches are selected on the device (``pnp_ransac_epnp_matches``), nothing is synchronised after the extractor."""
+        from . import pnp
+        det = self.extractor(image)
+        kpts2d = det["keypoints"][0]
+        inp = {"keypoints2d": kpts2d[None], "keypoints3d": self.db["keypoints3d"],
+               "descriptors2d_query": det["descriptors"][0][None].contiguous(), "descriptors3d_db": self.db["descriptors3d_db"],
+               "descriptors2d_db": self.db["descriptors2d_db"]}
+        pred, _ = self.matcher(inp, database=self.db_cache) if self.db_cache is not None else self.matcher(inp)
+        pose, mask, info = pnp.ransac_pnp_from_matches(K_crop, kpts2d, self.db["keypoints3d"][0], pred["matches0"], scale=scale, seed=seed)
+        return pose, mask, info, det
+
+    @torch.no_grad()
     def solve_pose(self, image, K_crop, scale=1000, seed=0):
         """image -> (pose_pred [3,4], pose_pred_homo [4,4], inliers [m,1]) like inference.py:140-155; numpy outputs, identity
         when fewer than 5 matches survive or the solve fails (eval_utils.py:40-42)."""

@@ -51,6 +51,28 @@ def ransac_pnp_device(K, pts_2d, pts_3d, scale=1.0, reproj_error=REPROJ_ERROR, i
     return pose, mask[:n], info
 
 
+@torch.no_grad()
+def ransac_pnp_from_matches(K, kpts2d, kpts3d, matches0, scale=1.0, reproj_error=REPROJ_ERROR, iterations=ITERATIONS, seed=0):
+    """inference.py:148-155 without a host round trip: kpts2d [n1,2] (extractor), kpts3d [N3,3] (database), matches0 [n1]
+    int64 (-1 = unmatched), all on the GPU -> (pose [3,4] float64, inlier_mask [n1] int32 per query keypoint, info [4])."""
+    if not (kpts2d.is_cuda and kpts3d.is_cuda and matches0.is_cuda):
+        raise RuntimeError("onepose_amd.pnp runs only on a ROCm GPU (there is no CPU fallback)")
+    dev = kpts2d.device
+    k2 = kpts2d.to(torch.float32).contiguous()
+    k3 = kpts3d.to(torch.float32).contiguous()
+    m0 = matches0.to(torch.int64).contiguous()
+    n1 = k2.shape[0]
+    lib = _native_pnp.load()
+    ws = torch.empty(lib.pnp_workspace_bytes(n1, iterations), device=dev, dtype=torch.uint8)
+    pose = torch.empty(3, 4, device=dev, dtype=torch.float64)
+    mask = torch.empty(n1, device=dev, dtype=torch.int32)
+    info = torch.empty(4, device=dev, dtype=torch.int32)
+    _native_pnp.check(lib.pnp_ransac_epnp_matches(k2.data_ptr(), k3.data_ptr(), m0.data_ptr(), n1, _k_array(K), float(scale),
+                                                  float(reproj_error), int(iterations), int(seed), pose.data_ptr(), mask.data_ptr(),
+                                                  info.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "pnp_ransac_epnp_matches")
+    return pose, mask, info
+
+
 def ransac_PnP(K, pts_2d, pts_3d, scale=1, iterations=ITERATIONS, seed=0):
     """ solve pnp -- drop-in for eval_utils.ransac_PnP (:18-42); numpy or tensor inputs, numpy outputs."""
     dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None

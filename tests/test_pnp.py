@@ -51,7 +51,7 @@ def test_every_declared_symbol_is_exported():
     lib = _native_pnp.load()
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pnp.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(pnp_[a-z0-9_]+)\s*\(", text)))
-    assert set(names) == set(_native_pnp.SYMBOLS) and len(names) == 5
+    assert set(names) == set(_native_pnp.SYMBOLS) and len(names) == 6
     for n in names:
         assert hasattr(lib, n)
     assert lib.pnp_workspace_bytes(300, 10000) > 10000 * 12 * 8 and lib.pnp_workspace_bytes(0, 10) == 0
@@ -153,3 +153,40 @@ def test_evaluator_matches_reference_golden(capsys):
     out = ev.summarize()
     assert {k: float(v) for k, v in out.items()} == g["summary"] and ev.cmd1 == []
     assert "1 cm 1 degree metric" in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_pose_from_matches_equals_host_selected_pose():
+    """pnp_ransac_epnp_matches (device-side selection of inference.py:148-152) == selecting on the host and calling pnp_ransac_epnp."""
+    import torch
+    from onepose_amd import pnp
+    p = synthetic.make_pnp_problem(400, 0.3, 0.4, 11)
+    rs = np.random.RandomState(0)
+    n1, n3 = 700, 900
+    kp3 = rs.uniform(-0.1, 0.1, (n3, 3)).astype(np.float32)
+    kp2 = rs.uniform(0, 512, (n1, 2)).astype(np.float32)
+    matches = -np.ones(n1, np.int64)
+    q = np.sort(rs.choice(n1, 400, replace=False))
+    d = rs.choice(n3, 400, replace=False)
+    kp2[q] = p["pts_2d"]
+    kp3[d] = p["pts_3d"]
+    matches[q] = d
+    K = p["K"]
+    pose_a, mask_a, info_a = pnp.ransac_pnp_from_matches(K, torch.from_numpy(kp2).cuda(), torch.from_numpy(kp3).cuda(),
+                                                          torch.from_numpy(matches).cuda(), scale=1000, iterations=512, seed=3)
+    valid = matches > -1
+    pose_b, mask_b, info_b = pnp.ransac_pnp_device(K, torch.from_numpy(kp2[valid]).cuda(), torch.from_numpy(kp3[matches[valid]]).cuda(),
+                                                   scale=1000, iterations=512, seed=3)
+    assert torch.equal(info_a, info_b) and torch.equal(pose_a, pose_b)              # same kernels on the same correspondences
+    full = np.zeros(n1, np.int32)
+    full[valid] = mask_b.cpu().numpy()
+    np.testing.assert_array_equal(mask_a.cpu().numpy(), full)
+    r_err, t_err = pnp.query_pose_error(pose_a.cpu().numpy(), p["pose_gt"])
+    assert r_err < 0.3 and t_err < 0.2
+    # fewer than 5 matches: identity pose, ok = 0 (eval_utils.py:40-42)
+    matches[:] = -1
+    matches[q[:3]] = d[:3]
+    pose_c, mask_c, info_c = pnp.ransac_pnp_from_matches(K, torch.from_numpy(kp2).cuda(), torch.from_numpy(kp3).cuda(),
+                                                          torch.from_numpy(matches).cuda(), scale=1000, iterations=64)
+    assert info_c.cpu().tolist()[:2] == [0, 0] and int(mask_c.sum()) == 0
+    np.testing.assert_array_equal(pose_c.cpu().numpy(), np.eye(4)[:3])
