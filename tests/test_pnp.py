@@ -139,6 +139,9 @@ def test_frame_matcher_solve_pose_plumbing():
     pose, homo, inliers = fm.solve_pose(torch.from_numpy(synthetic.make_image(1, 256, 256, 4)).cuda(), K)
     assert pose.shape == (3, 4) and homo.shape == (4, 4) and np.isfinite(pose).all()
     np.testing.assert_allclose(homo[3], [0, 0, 0, 1])
+    pose_d, mask_d, info_d, det = fm.solve_pose_device(torch.from_numpy(synthetic.make_image(1, 256, 256, 4)).cuda(), K)
+    np.testing.assert_array_equal(pose_d.cpu().numpy(), pose)           # device-side match selection == host-side selection
+    assert mask_d.shape[0] == det["keypoints"][0].shape[0] and int(info_d[1]) == len(inliers)
 
 
 def test_evaluator_matches_reference_golden(capsys):
