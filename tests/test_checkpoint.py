@@ -1,5 +1,4 @@
 """Lightning-layout checkpoint reading without pytorch_lightning / omegaconf (CPU)."""
-import pickle
 import sys
 import types
 

@@ -4,7 +4,6 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from onepose_amd import _native
 dev = torch.device("cuda:0")
 w = bench.Weights(dev); r = bench.Runner(dev, w)
 lib = w.engine.lib
