@@ -325,3 +325,31 @@ def test_frame_matcher_vs_oracle_chain():
         np.testing.assert_array_equal(out["mkpts3d"].cpu().numpy(), dbn["keypoints3d"][0][m[m > -1]])
         np.testing.assert_array_equal(out["mkpts2d"].cpu().numpy(), ref_det["keypoints"][0][m > -1])
         np.testing.assert_allclose(out["mconf"].cpu().numpy()[same[m > -1]], ref_pred["matching_scores0"][valid], atol=1e-4)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes_dense_and_keypoints(seed):
+    """Random image sizes / batch / radii: dense score map against the oracle, keypoints bit-exact on the HIP score map."""
+    rs = np.random.RandomState(1000 + seed)
+    b = int(rs.choice([1, 1, 2, 3]))
+    h, w = int(rs.randint(8, 200)), int(rs.randint(8, 260))
+    cfg = {"nms_radius": int(rs.randint(0, 7)), "remove_borders": int(rs.randint(0, 6)),
+           "keypoint_threshold": float(rs.choice([0.0, 0.005, 0.02])), "max_keypoints": int(rs.choice([-1, 30, 500]))}
+    mod, sd = make_module(seed, cfg)
+    img = synthetic.make_image(b, h, w, 77 + seed)
+    timg = torch.from_numpy(img).cuda()
+    score, dense = mod.engine.dense(timg)
+    out = mod(timg)
+    full = {**so.DEFAULT_CONFIG, **cfg}
+    for i in range(b):
+        feat = so.encoder(sd, img[i, 0])
+        np.testing.assert_allclose(score[i].cpu().numpy(), so.score_map(sd, feat), atol=ATOL_SCORE)
+        # discrete stages replayed by the oracle on the HIP score map: identical keypoints, order included
+        sm = score[i].cpu().numpy()
+        yx, sc = so.select_keypoints(so.simple_nms(sm, full["nms_radius"]), full["keypoint_threshold"], full["remove_borders"],
+                                     full["max_keypoints"])
+        np.testing.assert_array_equal(out["keypoints"][i].cpu().numpy(), yx[:, ::-1].astype(np.float32))
+        np.testing.assert_array_equal(out["scores"][i].cpu().numpy(), sc)
+        if len(yx):
+            d = out["descriptors"][i].cpu().numpy()
+            np.testing.assert_allclose(np.linalg.norm(d, axis=0), 1.0, atol=1e-5)
