@@ -193,6 +193,7 @@ using Mlp0Tile = GemmTile<128, MLP0_BN, 2, 2, false>;
 using Mlp0TileWide = GemmTile<256, MLP0_BN, 4, 1, false>;
 using Mlp0TileW8 = GemmTile<128, MLP0_BN, 4, 2, false>;    // 8 waves, one 32x32 MFMA tile each
 using Mlp0TileBig = GemmTile<128, 2 * MLP0_BN, 2, 4, false>;   // 8 waves, 128x128: a third fewer operand bytes per MFMA
+using Mlp0TileFlat = GemmTile<64, 2 * MLP0_BN, 2, 4, false>;   // 8 waves, 64x128: weights re-read less, activations more
 
 // per-workgroup timeline of mlp0_kernel (tools/trace_mlp0.py): 8 x u64 per workgroup
 // [hw_id, xcc_id, t_entry, shader cycles, t_after_mainloop, t_end, rt, ct], 100 MHz wall clock.
@@ -682,6 +683,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
     else if (t0 == 2) launch_mlp0_t<Mlp0TileW8>(W0, b0, w, s, hk);
     else if (t0 == 3) launch_mlp0_t<Mlp0TileBig>(W0, b0, w, s, hk);
+    else if (t0 == 4) launch_mlp0_t<Mlp0TileFlat>(W0, b0, w, s, hk);
     else launch_mlp0_t<Mlp0Tile>(W0, b0, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
 #ifdef GATSSPG_PROFILING_BUILD
