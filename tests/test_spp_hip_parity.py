@@ -353,3 +353,16 @@ def test_random_shapes_dense_and_keypoints(seed):
         if len(yx):
             d = out["descriptors"][i].cpu().numpy()
             np.testing.assert_allclose(np.linalg.norm(d, axis=0), 1.0, atol=1e-5)
+
+
+def test_batch_of_full_size_crops_is_per_image_identical():
+    """Four 512x512 crops in one launch sequence: every image's result is bit-identical to running it alone."""
+    mod, _ = make_module(0, {"nms_radius": 3, "max_keypoints": 4096})
+    img = torch.from_numpy(synthetic.make_image(4, 512, 512, 31)).cuda()
+    kp, sc, de, cnt = mod.forward_device(img)
+    for i in (0, 3):
+        one = mod(img[i:i + 1])
+        n = int(cnt[i, 0])
+        assert n == one["keypoints"][0].shape[0] == 4096
+        assert torch.equal(one["keypoints"][0], kp[i, :n]) and torch.equal(one["scores"][0], sc[i, :n])
+        assert torch.equal(one["descriptors"][0], de[i, :, :n])
