@@ -1,0 +1,94 @@
+"""Numerical study (CPU, numpy): would split-bf16 MFMA GEMMs stay inside the parity bar of the matcher?
+
+BASELINE.json configs[2] asks for "bf16 MFMA"; SURVEY App. B measured that NAIVE bf16 fails the 1e-4 / bit-exact bar.
+This script emulates the arithmetic of bf16 MFMA with fp32 accumulation for every GEMM of the forward (QKV / merge / MLP
+/ final_proj 1x1 convolutions and the score contraction; the KV sums and normalisations stay fp32) in three forms
+
+    bf16     : round both operands to bf16 (1 product)
+    bf16x3   : a = a1 + a2 (two bf16 terms each), products a1b1 + a1b2 + a2b1            (~2^-16 relative)
+    bf16x6   : a = a1 + a2 + a3 (exact split of fp32), all products down to order 2^-16   (~2^-24 relative: fp32-equivalent)
+
+and compares conf / matches with the plain fp32 oracle.  Not a test (not collected): run by hand,
+    python tests/studies/split_bf16_study.py [n1 n2]
+The result is quoted in DESIGN.md section 9.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from onepose_amd import synthetic  # noqa: E402
+from oracle import gatsspg_oracle as orc  # noqa: E402
+
+F32 = np.float32
+
+
+def bf16_trunc_split(x, terms):
+    """x (fp32) -> `terms` fp32 arrays, each exactly representable in bf16 (round-to-nearest-even on the leading term(s)),
+    summing to x up to the dropped tail."""
+    parts, r = [], x.astype(F32)
+    for _ in range(terms):
+        u = r.view(np.uint32)
+        rounded = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)      # RNE to bf16
+        p = rounded.view(F32)
+        parts.append(p)
+        r = (r - p).astype(F32)
+    return parts
+
+
+def split_matmul(a, b, mode):
+    """a [m,k] @ b [k,n] with the operand splitting of `mode`, fp32 accumulation."""
+    if mode == "fp32":
+        return a @ b
+    terms = {"bf16": 1, "bf16x3": 2, "bf16x6": 3}[mode]
+    ap, bp = bf16_trunc_split(a, terms), bf16_trunc_split(b, terms)
+    out = np.zeros((a.shape[0], b.shape[1]), F32)
+    max_order = {"bf16": 0, "bf16x3": 1, "bf16x6": 2}[mode]
+    pairs = sorted(((i, j) for i in range(terms) for j in range(terms) if i + j <= max_order), key=lambda t: -(t[0] + t[1]))
+    for i, j in pairs:                      # small terms first
+        out += ap[i] @ bp[j]
+    return out
+
+
+def run(mode, sd, data, hp):
+    orig = orc.conv1x1
+
+    def conv(w, b, x):
+        w2 = orc._f32(w).reshape(w.shape[0], w.shape[1])
+        y = np.stack([split_matmul(w2, orc._f32(x)[i], mode) for i in range(x.shape[0])])
+        if b is not None:
+            y = y + orc._f32(b)[None, :, None]
+        return y.astype(F32)
+
+    orc.conv1x1 = conv
+    try:
+        d2, d3 = orc.attentional_gnn(sd, hp, orc._f32(data["descriptors2d_query"]), orc._f32(data["descriptors3d_db"]),
+                                     orc._f32(data["descriptors2d_db"]))
+        m2 = orc.l2_normalize(orc.conv1x1(sd["final_proj.weight"], sd["final_proj.bias"], d2))
+        m3 = orc.l2_normalize(orc.conv1x1(sd["final_proj.weight"], sd["final_proj.bias"], d3))
+    finally:
+        orc.conv1x1 = orig
+    scores = np.stack([split_matmul(np.ascontiguousarray(m2[i].T), m3[i], mode) for i in range(m2.shape[0])]) / F32(hp["scale_factor"])
+    conf = orc.dual_softmax(scores.astype(F32))
+    return conf, orc.mutual_nn_match(conf, hp["match_threshold"])
+
+
+def main():
+    n1, n2 = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (500, 2000)
+    for label, sd, planted, thr in (("random weights, threshold 0", synthetic.make_state_dict(0), False, 0.0),
+                                    ("pass-through weights, planted matches, threshold 0.2", synthetic.make_passthrough_state_dict(0), True, 0.2)):
+        data = synthetic.make_inputs(b=1, n1=n1, n2=n2, num_leaf=8, seed=1, planted=planted)
+        hp = dict(orc.DEFAULT_HPARAMS, match_threshold=thr)
+        ref_conf, ref_m = run("fp32", sd, data, hp)
+        print(f"== {label}; N_2D={n1} N_3D={n2}; conf max {ref_conf.max():.3f}; valid matches {(ref_m['matches0'] > -1).sum()}")
+        for mode in ("bf16", "bf16x3", "bf16x6"):
+            conf, m = run(mode, sd, data, hp)
+            flips_row = int((conf.argmax(2) != ref_conf.argmax(2)).sum())
+            flips_m0 = int((m["matches0"] != ref_m["matches0"]).sum())
+            print(f"   {mode:7s} max|dconf| {np.abs(conf - ref_conf).max():.3e}  row-argmax flips {flips_row}/{n1}  matches0 differ {flips_m0}/{n1}")
+
+
+if __name__ == "__main__":
+    main()
