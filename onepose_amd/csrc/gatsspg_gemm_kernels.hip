@@ -2,6 +2,8 @@
 // linear-attention KV reduction / apply, and the N_2D x N_3D score contraction.
 // Reference maths: GATs_SuperGlue.py:69-128 (linear_attention, MultiHeadedAttention,
 // AttentionPropagation, MLP) and :209-218 (final_proj, normalize, score einsum, exp of the softmax).
+#include <string.h>
+
 #include "gemm_f32_mfma.h"
 #include "gatsspg_launch.h"
 #include <stdlib.h>
@@ -19,7 +21,7 @@ namespace gatsspg {
 using QkvTile = GemmTile<128, QKV_BN, 2, 2, false>;
 using QkvTileW8 = GemmTile<128, QKV_BN, 4, 2, false>;     // same tile on 8 waves (one 32x32 MFMA tile each)
 
-template <class T>
+template <class T, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS) void qkv_kv_kernel(const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
                                                             const float* __restrict__ Z, float* __restrict__ Qbuf,
                                                             float* __restrict__ kvpart, ColLayout L, int vec_store) {
@@ -32,9 +34,14 @@ __global__ __launch_bounds__(T::THREADS) void qkv_kv_kernel(const float* __restr
     const float* A = Wqkv + (size_t)rt * 128 * D;
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
-    gemm_mainloop<T>(
-        acc, smem, D / BK, [&](int kt) { return A + kt * BK; }, D,
-        [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
+    if constexpr (PREC == 1)
+        gemm_mainloop_bf3<T>(
+            acc, reinterpret_cast<unsigned short*>(smem), D / BK, [&](int kt) { return A + kt * BK; }, D,
+            [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
+    else
+        gemm_mainloop<T>(
+            acc, smem, D / BK, [&](int kt) { return A + kt * BK; }, D,
+            [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
@@ -204,7 +211,8 @@ unsigned long long* g_trace = nullptr;
 static constexpr unsigned long long* g_trace = nullptr;
 #endif
 
-template <class T, int ABL = 0>
+// PREC = 0: exact fp32 MFMA (default).  PREC = 1: split-bf16 ("bf16x3") main loop, opt-in (GATSSPG_MLP0_PREC=bf16x3).
+template <class T, int ABL = 0, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                    const float* __restrict__ Z, const float* __restrict__ MSG,
                                                    float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
@@ -226,7 +234,12 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
     const int ch0 = ABL == 5 ? 0 : c0;
     auto al = [&](int kt) { return Ah + kt * BK; };
     auto bl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : MSG + (size_t)(kt - 8) * BK * ld) + ch0; };
-    gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL)>(acc, smem, 512 / BK, al, 512, bl, ld);
+    if constexpr (PREC == 1) {
+        gemm_mainloop_bf3<T>(acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, al, 512, bl, ld);
+        __syncthreads();
+    } else {
+        gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL)>(acc, smem, 512 / BK, al, 512, bl, ld);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
     const unsigned long long t_loop = trace ? wall_clock64() : 0;
@@ -352,7 +365,7 @@ using Mlp3TileWide = GemmTile<64, 128, 1, 4, false>;
 using Mlp3TileTallW8 = GemmTile<128, 64, 4, 2, false>;   // 8 waves
 using Mlp3TileWideW8 = GemmTile<64, 128, 2, 4, false>;   // 8 waves
 
-template <class T, int ABL = 0>
+template <class T, int ABL = 0, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
                                                    const float* __restrict__ U, const float* __restrict__ stats,
                                                    float* __restrict__ Z, ColLayout L, int vec_store) {
@@ -391,8 +404,12 @@ __global__ __launch_bounds__(T::THREADS) void mlp3_kernel(const float* __restric
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fmaxf((v[q] - ms.x) * ms.y, 0.f);
     };
-    gemm_mainloop_ex<T, decltype(al), decltype(bl), decltype(xm), decltype(xr), decltype(bx), true, ABL>(
-        acc, smem, 512 / BK, al, 512, bl, ld, xm, xr, bx);
+    if constexpr (PREC == 1)
+        gemm_mainloop_bf3_ex<T, decltype(al), decltype(bl), decltype(xm), decltype(xr), decltype(bx), true>(
+            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, al, 512, bl, ld, xm, xr, bx);
+    else
+        gemm_mainloop_ex<T, decltype(al), decltype(bl), decltype(xm), decltype(xr), decltype(bx), true, ABL>(
+            acc, smem, 512 / BK, al, 512, bl, ld, xm, xr, bx);
     if (vec_store) {
         store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [](int, float v) { return v; });
         return;
@@ -617,23 +634,35 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
+// opt-in split-bf16 ("bf16x3") main loop (gemm_f32_mfma.h): GATSSPG_PREC=bf16x3 switches the kernels where it pays
+// (mlp0: 42.9 -> 34.9 us, qkv_kv: 38.0 -> 34.2 us; 1134 -> 1333 frames/s), or per kernel GATSSPG_MLP0_PREC /
+// GATSSPG_QKV_PREC / GATSSPG_MLP3_PREC (mlp3's 64x64 tile does not gain: 27.9 -> 28.5 us, so it is not in the group).
+// The default is the exact fp32 MFMA path.
+static bool split_bf16_enabled(const char* kernel_env, bool in_group = true) {
+    const char* a = getenv("GATSSPG_PREC");
+    const char* b = getenv(kernel_env);
+    return (in_group && a && !strcmp(a, "bf16x3")) || (b && !strcmp(b, "bf16x3"));
+}
 static int vec_store_enabled() {
     static const int v = env_int("GATSSPG_VSTORE", 1);
     return v;
 }
 
-template <class T>
+template <class T, int PREC = 0>
 static void launch_qkv_t(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     const int NT = active_tiles(w.L);
-    auto kern = qkv_kv_kernel<T>;
+    auto kern = qkv_kv_kernel<T, PREC>;
     GATSSPG_BIG_LDS_ONCE(kern);
-    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, kern, dim3(xcd_grid(6, NT)), dim3(T::THREADS), shaped_lds(smem_bytes<T>(), 6 * NT), s,
+    size_t lds = smem_bytes<T>();
+    if (PREC == 1 && Bf3Layout<T>::SMEM_BYTES > lds) lds = Bf3Layout<T>::SMEM_BYTES;
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, kern, dim3(xcd_grid(6, NT)), dim3(T::THREADS), shaped_lds(lds, 6 * NT), s,
                    Wqkv, bqkv, w.Z, w.Q, w.kvpart, w.L, vec_store_enabled());
 }
 
 void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     static const int tq = env_int("GATSSPG_QKV_TILE", 1);   // 1 (default): the 128x64 tile on 8 waves (38.0 vs 40.1 us); 0: on 4
-    if (tq == 1) launch_qkv_t<QkvTileW8>(Wqkv, bqkv, w, s, hk);
+    if (split_bf16_enabled("GATSSPG_QKV_PREC")) launch_qkv_t<QkvTileW8, 1>(Wqkv, bqkv, w, s, hk);
+    else if (tq == 1) launch_qkv_t<QkvTileW8>(Wqkv, bqkv, w, s, hk);
     else launch_qkv_t<QkvTile>(Wqkv, bqkv, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3(KVP / 64, w.nseg * H), dim3(1024), 0, s, w.kvpart,
                    w.kvfin, w.L);
@@ -647,23 +676,26 @@ void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook
 }
 
 
-template <class T, int ABL = 0>
+template <class T, int ABL = 0, int PREC = 0>
 static void launch_mlp0_t(const float* W0, const float* b0, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    auto kern = mlp0_kernel<T, ABL>;
+    auto kern = mlp0_kernel<T, ABL, PREC>;
     GATSSPG_BIG_LDS_ONCE(kern);
     const int vec_store = vec_store_enabled();
     const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
+    size_t lds = smem_bytes<T>();
+    if (PREC == 1 && Bf3Layout<T>::SMEM_BYTES > lds) lds = Bf3Layout<T>::SMEM_BYTES;
     GATSSPG_LAUNCH(hk, KID_MLP0, s, kern, dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
-                   shaped_lds(smem_bytes<T>(), 512 / T::BM * NT), s, W0, b0, w.Z, w.MSG, w.U, w.statpart, w.L, g_trace,
-                   vec_store);
+                   shaped_lds(lds, 512 / T::BM * NT), s, W0, b0, w.Z, w.MSG, w.U, w.statpart, w.L, g_trace, vec_store);
 }
-template <class T, int ABL = 0>
+template <class T, int ABL = 0, int PREC = 0>
 static void launch_mlp3_t(const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    auto kern = mlp3_kernel<T, ABL>;
+    auto kern = mlp3_kernel<T, ABL, PREC>;
     GATSSPG_BIG_LDS_ONCE(kern);
     const int NT = active_tiles(w.L) / (T::BN / 64);
-    GATSSPG_LAUNCH(hk, KID_MLP3, s, kern, dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS),
-                   shaped_lds(smem_bytes<T>(), 256 / T::BM * NT), s, W3, b3, w.U, w.stats, w.Z, w.L, vec_store_enabled());
+    size_t lds = smem_bytes<T>();
+    if (PREC == 1 && Bf3Layout<T>::SMEM_BYTES > lds) lds = Bf3Layout<T>::SMEM_BYTES;
+    GATSSPG_LAUNCH(hk, KID_MLP3, s, kern, dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), shaped_lds(lds, 256 / T::BM * NT), s,
+                   W3, b3, w.U, w.stats, w.Z, w.L, vec_store_enabled());
 }
 
 void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const Workspace& w, hipStream_t s,
@@ -680,7 +712,9 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else if (t0 == 16) launch_mlp0_t<Mlp0Tile, 6>(W0, b0, w, s, hk);   // every load L1-hot
     else
 #endif
-    if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
+    static const bool bf3 = split_bf16_enabled("GATSSPG_MLP0_PREC"), bf3m3 = split_bf16_enabled("GATSSPG_MLP3_PREC", false);
+    if (bf3) launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, w, s, hk);
+    else if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
     else if (t0 == 2) launch_mlp0_t<Mlp0TileW8>(W0, b0, w, s, hk);
     else if (t0 == 3) launch_mlp0_t<Mlp0TileBig>(W0, b0, w, s, hk);
     else if (t0 == 4) launch_mlp0_t<Mlp0TileFlat>(W0, b0, w, s, hk);
@@ -692,7 +726,8 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3>(W3, b3, w, s, hk);   // steady-state loop cut: fixed cost only
     else
 #endif
-    if (t3 == 1) launch_mlp3_t<Mlp3TileTall>(W3, b3, w, s, hk);
+    if (bf3m3) launch_mlp3_t<Mlp3Tile, 0, 1>(W3, b3, w, s, hk);
+    else if (t3 == 1) launch_mlp3_t<Mlp3TileTall>(W3, b3, w, s, hk);
     else if (t3 == 2) launch_mlp3_t<Mlp3TileWide>(W3, b3, w, s, hk);
     else if (t3 == 3) launch_mlp3_t<Mlp3TileTallW8>(W3, b3, w, s, hk);
     else if (t3 == 4) launch_mlp3_t<Mlp3TileWideW8>(W3, b3, w, s, hk);

@@ -291,6 +291,166 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     }
 }
 
+// =====================================================================================================
+// Split-bf16 variant of the main loop ("bf16x3"): fp32 operands in HBM, each split on the LDS write into two bf16 terms
+// x = x1 + x2 (x1 = RNE_bf16(x), x2 = RNE_bf16(x - x1)); the product is a1*b1 + a1*b2 + a2*b1 on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (3 x 32 cycles per 32x32x16 block instead of 8 x 64 for the f32 MFMA).
+// tests/studies/split_bf16_study.py: conf within 5e-7 of the fp32 forward and every match identical at the headline
+// shape.  OPT-IN (GATSSPG_MLP0_PREC=bf16x3): the default path stays exact fp32.
+// LDS images (bf16): A planes [BM][40] (k contiguous, 80-byte rows: 16-byte fragment reads), B planes [BN][40] (the
+// [K][N] activation slab is transposed on the write so that a lane's 8 k values are contiguous).
+// Same pipeline as gemm_mainloop_ex: two register sets, prefetch distance 2, one barrier per slab.
+// =====================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_rne_bits(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void bf16_split(float x, unsigned short& hi, unsigned short& lo) {
+    const unsigned h = bf16_rne_bits(x);
+    hi = (unsigned short)h;
+    lo = (unsigned short)bf16_rne_bits(x - __uint_as_float(h << 16));
+}
+
+template <class T>
+struct Bf3Layout {
+    static constexpr int KS = 40;                                   // bf16 per row (32 + 8 pad)
+    static constexpr int A_PLANE = T::BM * KS, B_PLANE = T::BN * KS;   // in bf16 elements
+    static constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;         // hi + lo of both operands
+    static constexpr size_t SMEM_BYTES = 2 * (size_t)STAGE * 2;     // two stages
+};
+
+// x_mean / x_rstd / bxform: as in gemm_mainloop_ex (per-k-row aux values, applied to the B registers before the split).
+template <class T, class ASlab, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX>
+__device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, ASlab a_slab,
+                                                     int lda, BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform) {
+    static_assert(!T::AKM && !T::BU, "row-major A, aligned B");
+    using LY = Bf3Layout<T>;
+    constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN, KS = LY::KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    unsigned a_goff[T::A_VEC], b_goff[T::B_VEC];
+    int a_soff[T::A_VEC], b_sk[T::B_VEC], b_sc[T::B_VEC];
+#pragma unroll
+    for (int p = 0; p < T::A_VEC; ++p) {
+        const int idx = p * T::THREADS + tid;
+        const int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
+        a_goff[p] = 4u * (unsigned)(r * lda + c);
+        a_soff[p] = r * KS + c;
+    }
+#pragma unroll
+    for (int p = 0; p < T::B_VEC; ++p) {
+        const int idx = p * T::THREADS + tid;
+        const int k = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
+        b_goff[p] = 4u * (unsigned)(k * ldb + c);
+        b_sk[p] = k;
+        b_sc[p] = c;
+    }
+    vf4 ra0[T::A_VEC], rb0[T::B_VEC], ra1[T::A_VEC], rb1[T::B_VEC];
+    float2 rx0[T::B_VEC], rx1[T::B_VEC];
+    auto gload = [&](int kt, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC], float2(&rx)[T::B_VEC]) {
+#pragma unroll
+        for (int q = 0; q < T::A_VEC; ++q) ra[q] = ldg4_off(a_slab(kt), a_goff[q]);
+#pragma unroll
+        for (int q = 0; q < T::B_VEC; ++q) {
+            rb[q] = ldg4_off(b_slab(kt), b_goff[q]);
+            if constexpr (HAS_AUX) rx[q] = make_float2(x_mean(kt)[b_sk[q]], x_rstd(kt)[b_sk[q]]);
+        }
+    };
+    auto swrite = [&](unsigned short* stage, const vf4(&ra)[T::A_VEC], const vf4(&rb)[T::B_VEC], const float2(&rx)[T::B_VEC]) {
+        unsigned short* Ahi = stage;
+        unsigned short* Alo = stage + LY::A_PLANE;
+        unsigned short* Bhi = stage + 2 * LY::A_PLANE;
+        unsigned short* Blo = Bhi + LY::B_PLANE;
+#pragma unroll
+        for (int p = 0; p < T::A_VEC; ++p) {
+            u16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned short hh, ll;
+                bf16_split(ra[p][e], hh, ll);
+                h[e] = hh; l[e] = ll;
+            }
+            *reinterpret_cast<u16x4*>(Ahi + a_soff[p]) = h;      // 4 consecutive k of one row: 8-byte stores
+            *reinterpret_cast<u16x4*>(Alo + a_soff[p]) = l;
+        }
+#pragma unroll
+        for (int p = 0; p < T::B_VEC; ++p) {
+            vf4 v = rb[p];
+            if constexpr (HAS_AUX) bxform(v, rx[p]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                         // transpose: column c + e, row k
+                unsigned short hh, ll;
+                bf16_split(v[e], hh, ll);
+                Bhi[(b_sc[p] + e) * KS + b_sk[p]] = hh;
+                Blo[(b_sc[p] + e) * KS + b_sk[p]] = ll;
+            }
+        }
+    };
+    auto compute = [&](const unsigned short* stage) {
+        const unsigned short* Ahi = stage;
+        const unsigned short* Alo = stage + LY::A_PLANE;
+        const unsigned short* Bhi = stage + 2 * LY::A_PLANE;
+        const unsigned short* Blo = Bhi + LY::B_PLANE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                             // two k16 steps per 32-wide slab
+            const int ko = 16 * s + 8 * half;                     // the same k assignment for A and B fragments
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row = (wm * TM + tm) * 32 + l31;
+                ah[tm] = *reinterpret_cast<const bf16x8*>(Ahi + row * KS + ko);
+                al[tm] = *reinterpret_cast<const bf16x8*>(Alo + row * KS + ko);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = (wn * TN + tn) * 32 + l31;
+                bh[tn] = *reinterpret_cast<const bf16x8*>(Bhi + col * KS + ko);
+                bl[tn] = *reinterpret_cast<const bf16x8*>(Blo + col * KS + ko);
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {                 // small terms first
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                }
+        }
+    };
+    unsigned short* buf0 = smem;
+    unsigned short* buf1 = smem + LY::STAGE;
+    const int last = KT - 1;
+    gload(0, ra0, rb0, rx0);
+    swrite(buf0, ra0, rb0, rx0);
+    gload(min(1, last), ra0, rb0, rx0);
+    gload(min(2, last), ra1, rb1, rx1);
+    __syncthreads();
+    for (int i = 0; i < KT; i += 2) {
+        compute(buf0);
+        swrite(buf1, ra0, rb0, rx0);
+        asm volatile("" ::: "memory");
+        gload(min(i + 3, last), ra0, rb0, rx0);
+        __syncthreads();
+        compute(buf1);
+        swrite(buf0, ra1, rb1, rx1);
+        asm volatile("" ::: "memory");
+        gload(min(i + 4, last), ra1, rb1, rx1);
+        __syncthreads();
+    }
+}
+
+template <class T, class ASlab, class BSlab>
+__device__ __forceinline__ void gemm_mainloop_bf3(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, ASlab a_slab, int lda,
+                                                  BSlab b_slab, int ldb) {
+    auto nox = [](int) { return static_cast<const float*>(nullptr); };
+    gemm_mainloop_bf3_ex<T, ASlab, BSlab, decltype(nox), decltype(nox), NoXform, false>(acc, smem, KT, a_slab, lda, b_slab, ldb, nox,
+                                                                                       nox, NoXform());
+}
+
 // convenience wrapper without per-row aux / transform
 template <class T, class ASlab, class BSlab, int ABLATE = 0, class BCol = IdentityCol>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,

@@ -31,7 +31,8 @@ sys.exit(0 if ok else 1)
 @pytest.mark.parametrize("env", [{"GATSSPG_MLP0_TILE": "0"}, {"GATSSPG_MLP0_TILE": "1"}, {"GATSSPG_MLP0_TILE": "2"},
                                  {"GATSSPG_MLP0_TILE": "3"}, {"GATSSPG_MLP0_TILE": "4"}, {"GATSSPG_MLP3_TILE": "1"}, {"GATSSPG_MLP3_TILE": "2"},
                                  {"GATSSPG_GATS_TILE": "8"}, {"GATSSPG_LDS_SHAPING": "1"}, {"GATSSPG_VSTORE": "0"},
-                                 {"GATSSPG_QKV_TILE": "0"}, {"GATSSPG_MLP3_TILE": "3"}, {"GATSSPG_MLP3_TILE": "4"}, {"GATSSPG_SCORE_TILE": "0"}])
+                                 {"GATSSPG_QKV_TILE": "0"}, {"GATSSPG_MLP3_TILE": "3"}, {"GATSSPG_MLP3_TILE": "4"}, {"GATSSPG_SCORE_TILE": "0"},
+                                 {"GATSSPG_PREC": "bf16x3"}, {"GATSSPG_MLP3_PREC": "bf16x3"}])
 def test_tile_variant_parity(env):
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-c", SNIPPET], env=e, capture_output=True, text=True, timeout=300)
