@@ -600,7 +600,7 @@ def main():
         achieved = fl / (kern_ms * 1e-3) / 1e12
         # opt-in split-bf16 build knob (never the headline): the timed kernel issues 3 bf16 MFMA products per algorithmic
         # flop, so its roofline is priced on executed flops against the bf16 peak
-        split = (os.environ.get("GATSSPG_PREC") == "bf16x3" and args.kernel in ("mlp0", "qkv_kv")) or \
+        split = (os.environ.get("GATSSPG_PREC") == "bf16x3" and args.kernel in ("mlp0", "qkv_kv", "mlp3")) or \
             os.environ.get(f"GATSSPG_{args.kernel.upper().split('_')[0]}_PREC") == "bf16x3"
         peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         if split:
@@ -611,7 +611,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic unit-norm desc_2d/desc_3d, N_2D=1000 N_3D=7000 d=256 "
                                    "num_leaf=8, batch=1 per step, fp32, random-init GATsSPG weights (12 GNN layers)",
-                       "gemm_precision": "bf16x3 split MFMA in mlp0 / qkv_kv (opt-in knob, not the headline configuration)"
+                       "gemm_precision": "bf16x3 split MFMA in mlp0 / qkv_kv / mlp3 (opt-in knob, not the headline configuration)"
                        if os.environ.get("GATSSPG_PREC") == "bf16x3" else "f32 MFMA (exact)",
                        "n_2d": N1, "n_3d": N2, "num_leaf": NUM_LEAF, "batch": runner.b, "frames_per_gpu": K,
                        "frames_in_flight_per_gpu": S, "single_frame_latency_ms": round(latency * 1e3, 4),

@@ -634,9 +634,9 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-// opt-in split-bf16 ("bf16x3") main loop (gemm_f32_mfma.h): GATSSPG_PREC=bf16x3 switches the kernels where it pays
-// (mlp0: 42.9 -> 34.9 us, qkv_kv: 38.0 -> 34.2 us; 1134 -> 1333 frames/s), or per kernel GATSSPG_MLP0_PREC /
-// GATSSPG_QKV_PREC / GATSSPG_MLP3_PREC (mlp3's 64x64 tile does not gain: 27.9 -> 28.5 us, so it is not in the group).
+// opt-in split-bf16 ("bf16x3") main loop (gemm_f32_mfma.h): GATSSPG_PREC=bf16x3 switches mlp0 (42.9 -> 34.9 us),
+// qkv_kv (38.0 -> 34.2 us) and mlp3 (27.9 -> 22.5 us on the 128x64 / 8-wave tile; its default 64x64 tile does not gain):
+// 1134 -> 1394 frames/s.  Per kernel: GATSSPG_MLP0_PREC / GATSSPG_QKV_PREC / GATSSPG_MLP3_PREC.
 // The default is the exact fp32 MFMA path.
 static bool split_bf16_enabled(const char* kernel_env, bool in_group = true) {
     const char* a = getenv("GATSSPG_PREC");
@@ -712,7 +712,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else if (t0 == 16) launch_mlp0_t<Mlp0Tile, 6>(W0, b0, w, s, hk);   // every load L1-hot
     else
 #endif
-    static const bool bf3 = split_bf16_enabled("GATSSPG_MLP0_PREC"), bf3m3 = split_bf16_enabled("GATSSPG_MLP3_PREC", false);
+    static const bool bf3 = split_bf16_enabled("GATSSPG_MLP0_PREC"), bf3m3 = split_bf16_enabled("GATSSPG_MLP3_PREC");
     if (bf3) launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, w, s, hk);
     else if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
     else if (t0 == 2) launch_mlp0_t<Mlp0TileW8>(W0, b0, w, s, hk);
@@ -726,7 +726,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3>(W3, b3, w, s, hk);   // steady-state loop cut: fixed cost only
     else
 #endif
-    if (bf3m3) launch_mlp3_t<Mlp3Tile, 0, 1>(W3, b3, w, s, hk);
+    if (bf3m3) launch_mlp3_t<Mlp3TileTallW8, 0, 1>(W3, b3, w, s, hk);   // 128x64 on 8 waves: the 64x64 tile does not gain from the split loop
     else if (t3 == 1) launch_mlp3_t<Mlp3TileTall>(W3, b3, w, s, hk);
     else if (t3 == 2) launch_mlp3_t<Mlp3TileWide>(W3, b3, w, s, hk);
     else if (t3 == 3) launch_mlp3_t<Mlp3TileTallW8>(W3, b3, w, s, hk);

@@ -429,6 +429,8 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
     gload(min(1, last), ra0, rb0, rx0);
     gload(min(2, last), ra1, rb1, rx1);
     __syncthreads();
+    // step i: MFMAs of slab i, then slab i+1 (in registers since step i-2) is split and written to the free buffer and the
+    // freed registers start loading slab i+3 (issuing the writes / loads before the MFMAs measured no better: 36.0 vs 34.9 us)
     for (int i = 0; i < KT; i += 2) {
         compute(buf0);
         swrite(buf1, ra0, rb0, rx0);
