@@ -67,9 +67,9 @@ def kernel_flops(name, n1, n2):
 class Weights:
     """Random-init GATsSPG weights packed once on the device (shared by every in-flight frame)."""
 
-    def __init__(self, device):
+    def __init__(self, device, precision="fp32"):
         sd = synthetic.make_state_dict(0)
-        self.model = GATsSuperGlue(HP).eval()
+        self.model = GATsSuperGlue(HP, precision=precision).eval()
         self.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
         self.model.to(device)
         self.engine = self.model.engine
@@ -81,18 +81,22 @@ class Runner:
     """One in-flight frame slot: its own HIP stream, workspace and output buffers, everything
     pre-allocated; step() is a single C-ABI call that enqueues one forward on the slot's stream."""
 
-    def __init__(self, device, weights, shared_inputs=None, b=1, n1=N1, n2=N2, n_query_frames=4, own_stream=False):
+    def __init__(self, device, weights, shared_inputs=None, b=1, n1=N1, n2=N2, n_query_frames=4, own_stream=False,
+                 golden_seed=None):
         self.device = device
         self.b, self.n1, self.n2 = b, n1, n2
         if shared_inputs is None:
             # the 3D database (descriptors3d_db + its leaves) is per object and constant across query
-            # frames (inference.py:113-130); query descriptors rotate over a small pool of frames
-            data = synthetic.make_inputs(b, n1, n2, NUM_LEAF, seed=1)
+            # frames (inference.py:113-130); query descriptors rotate over a small pool of frames.  The database and pool
+            # slot 0 are the inputs of the reference-run golden of this shape (golden_seed), so the line can carry a parity
+            # number against the reference's own output; the other slots are fresh random unit-norm frames.
+            data = synthetic.make_inputs(b, n1, n2, NUM_LEAF, seed=1 if golden_seed is None else golden_seed)
             d3 = torch.from_numpy(data["descriptors3d_db"]).to(device)
             d2db = torch.from_numpy(data["descriptors2d_db"]).to(device)
             rs = np.random.RandomState(7)
             q = rs.standard_normal((n_query_frames, b, D, n1)).astype(np.float32)
             q /= np.linalg.norm(q, axis=2, keepdims=True)
+            q[0] = data["descriptors2d_query"]
             shared_inputs = (d3, d2db, [torch.from_numpy(q[i]).to(device) for i in range(n_query_frames)])
         self.shared_inputs = shared_inputs
         self.d3, self.d2db, self.queries = shared_inputs
@@ -188,9 +192,11 @@ def cpu_baseline(max_seconds=15.0):
     data = {k: torch.from_numpy(v) for k, v in synthetic.make_inputs(1, N1, N2, NUM_LEAF, seed=1).items()}
     hp = dict(gatsspg_oracle.DEFAULT_HPARAMS)
     dt, n, threads = _timed_cpu(lambda: torch_oracle.forward(sd, data, hp), max_seconds)
-    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": int(threads), "kind": "port",
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": int(threads), "threads_used": int(threads),
+            "host_cores": int(os.cpu_count() or 1), "kind": "port",
             "sample": f"{n} frame(s) after warm-up at the fastest of 3 thread counts, N_2D={N1} N_3D={N2} num_leaf={NUM_LEAF} batch 1 fp32, stock PyTorch CPU ops "
-                      f"restating GATsSuperGlue.forward incl. the literal h@W GEMMs (oracle/torch_oracle.py), {dt * 1e3:.0f} ms/frame"}
+                      f"restating GATsSuperGlue.forward incl. the literal h@W GEMMs (oracle/torch_oracle.py -- a port: /root/reference does "
+                      f"not travel to the GPU box; the port is pinned against reference-run goldens in tests/), {dt * 1e3:.0f} ms/frame"}
 
 
 # =====================================================================================================
@@ -257,7 +263,8 @@ def spp_cpu_baseline(max_seconds=10.0):
     sd = {k: torch.from_numpy(v) for k, v in synthetic.make_spp_state_dict(0).items()}
     img = torch.from_numpy(synthetic.make_image(1, SPP_H, SPP_W, 11))
     dt, n, threads = _timed_cpu(lambda: tso.forward(sd, img, SPP_CFG), max_seconds)
-    return {"value": round(1.0 / dt, 3), "unit": "images/s", "cores": int(threads), "kind": "port",
+    return {"value": round(1.0 / dt, 3), "unit": "images/s", "cores": int(threads), "threads_used": int(threads),
+            "host_cores": int(os.cpu_count() or 1), "kind": "port",
             "sample": f"{n} image(s) {SPP_H}x{SPP_W} after warm-up at the fastest of 3 thread counts, stock PyTorch CPU ops restating SuperPoint.forward "
                       f"(oracle/torch_superpoint_oracle.py), {dt * 1e3:.0f} ms/image"}
 
@@ -488,12 +495,85 @@ def main_pnp(args):
     print(json.dumps(out), flush=True)
 
 
+# =====================================================================================================
+# matcher (the headline path)
+# =====================================================================================================
+# name -> workload.  "golden": the reference-run summary golden (tests/golden/make_bench_golden.py) whose inputs slot 0 of
+# the frame pool reproduces, so the line carries a post-run parity number against the REFERENCE's output.
+CONFIGS = {
+    "headline": dict(b=1, n1=1000, n2=7000, precision="fp32", golden="head_rand",
+                     what="BASELINE configs[1]: synthetic unit-norm desc_2d/desc_3d, N_2D=1000 N_3D=7000 d=256 num_leaf=8, "
+                          "batch=1 per step, fp32, random-init GATsSPG weights (12 GNN layers)"),
+    "bf16x3": dict(b=1, n1=1000, n2=7000, precision="bf16x3", golden="head_rand",
+                   what="headline shape (1000/7000, batch 1) with the attention-layer GEMMs on split-bf16 MFMA (3 bf16 products "
+                        "per fp32 product); never the headline value"),
+    "fp32-b8": dict(b=8, n1=1000, n2=7000, precision="fp32", golden="head_b8",
+                    what="BASELINE configs[2]'s per-GPU share in fp32: 8 frames of 1000/7000 per step"),
+    "bf16x3-b8": dict(b=8, n1=1000, n2=7000, precision="bf16x3", golden="head_b8",
+                      what="BASELINE configs[2] ('bf16 MFMA, 64 frames sharded 8 per GPU'): 8 frames of 1000/7000 per step, "
+                           "attention-layer GEMMs on split-bf16 MFMA; reported separately, never the headline value"),
+    "stress": dict(b=1, n1=1000, n2=20000, precision="fp32", golden="stress_rand",
+                   what="BASELINE configs[4] shape: N_3D=20000 dense cloud, batch 1 per step, fp32"),
+    "stress-b4": dict(b=4, n1=1000, n2=20000, precision="fp32", golden=None,
+                      what="BASELINE configs[4]'s per-GPU share: 4 frames of 1000/20000 per step, fp32"),
+}
+GOLDEN_SEEDS = {"head_rand": 1, "head_b8": 3, "stress_rand": 5}   # make_inputs seeds of tests/golden/make_bench_golden.py
+
+
+def golden_parity(runner, cfg):
+    """One forward of the golden's inputs on the timed code path, compared with the REFERENCE's outputs committed under
+    tests/golden/ (conf sub-sample, row/col maxima, raw arg-max indices).  No oracle involved."""
+    name = cfg["golden"]
+    path = os.path.join(ROOT, "tests", "golden", f"bench_{name}.npz")
+    if name is None or not os.path.exists(path):
+        return None
+    g = np.load(path)
+    with open(os.path.join(ROOT, "tests", "golden", "bench_golden_meta.json")) as f:
+        sub = json.load(f)["cases"][name]["sub"]
+    with torch.cuda.stream(runner.stream):
+        runner.step(0)                     # pool slot 0 = the golden's query frame(s)
+    torch.cuda.synchronize()
+    c = runner.conf.cpu().numpy()
+    err = max(float(np.abs(c[:, ::sub[0], ::sub[1]] - g["conf_sub"]).max()), float(np.abs(c.max(2) - g["conf_rowmax"]).max()),
+              float(np.abs(c.max(1) - g["conf_colmax"]).max()))
+    flips = int((c.argmax(2) != g["indices0_raw"]).sum() + (c.argmax(1) != g["indices1_raw"]).sum())
+    return {"against": f"tests/golden/bench_{name}.npz (reference GATsSuperGlue.forward run on CPU fp32, same seeded inputs)",
+            "max_abs_conf_err": err, "argmax_flips": flips, "argmax_checked": int(c.shape[0] * (c.shape[1] + c.shape[2]))}
+
+
+def self_launch(args, argv):
+    """--gpus N without a torchrun environment: re-exec under torch.distributed.run, one rank per GPU (RCCL)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+class DryRunner:
+    """CPU stand-in for a frame slot (bench.py --dry-run): exercises the launcher / barrier / metrics-gather / JSON path
+    without a GPU.  Never produces a benchmark number (the line says data: "dry-run")."""
+    b = 1
+
+    def step(self, i):
+        time.sleep(0.002)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=5, help="the K-step timed pass is repeated this many times; the median is reported")
     ap.add_argument("--streams", type=int, default=3, help="query frames kept in flight per GPU (one HIP stream each)")
+    ap.add_argument("--config", default="headline", choices=list(CONFIGS),
+                    help="workload: 'headline' = BASELINE configs[1] (the value the driver records); the others are "
+                         "separately reported lines (config.workload names them)")
     ap.add_argument("--amortised", action="store_true",
                     help="also report the database-cache mode (query-independent part of the first 3 GNN layers "
                          "precomputed once per object); informative, never the headline value")
@@ -505,7 +585,16 @@ def main():
     ap.add_argument("--torch-eager", action="store_true",
                     help="informative baseline: the reference algorithm through stock PyTorch-ROCm ops on this GPU")
     ap.add_argument("--pnp", action="store_true", help="benchmark the RANSAC-EPnP pose solver (informative)")
+    ap.add_argument("--tuning-lib", action="store_true",
+                    help="load lib*_tuning.so (python -m onepose_amd.build_ext --tuning): GATSSPG_<KNOB> environment knobs select "
+                         "alternative tile shapes for A/B runs; the line is labelled and is never a headline number")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: stub steps on CPU over gloo -- tests the --gpus N launcher, barrier, metrics gather and JSON line")
     args = ap.parse_args()
+    if args.tuning_lib:
+        from onepose_amd import build_ext
+        _native.LIB_PATH = build_ext.tuning_path(build_ext.LIB_PATH)
+        _native_spp.LIB_PATH = build_ext.tuning_path(build_ext.SPP_LIB_PATH)
     if args.pnp:
         return main_pnp(args)
     if args.torch_eager:
@@ -515,33 +604,69 @@ def main():
     if args.extractor:
         return main_extractor(args)
 
-    rank, local_rank, world = sharding.init_process_group()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    device = torch.device("cuda", local_rank % torch.cuda.device_count())
-    torch.cuda.set_device(device)
+    # ---- one process per GPU.  Under torchrun WORLD_SIZE must equal --gpus; without it, --gpus N > 1 spawns the ranks itself.
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        if not args.dry_run and (not torch.cuda.is_available() or torch.cuda.device_count() < args.gpus):
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count() if torch.cuda.is_available() else 0} "
+                             "GPU(s) visible; refusing to fall back to fewer ranks")
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if launched and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus})")
+    rank, local_rank, world = sharding.init_process_group(backend="gloo" if args.dry_run else None)
+    cfg = CONFIGS[args.config]
+    K, W, S, R = args.steps, args.warmup, max(1, args.streams), max(1, args.reps)
 
-    weights = Weights(device)
-    K, W, S = args.steps, args.warmup, max(1, args.streams)
-    base = Runner(device, weights)
-    slots = [Runner(device, weights, base.shared_inputs, own_stream=True) for _ in range(S)]
-    torch.cuda.synchronize(device)
+    if args.dry_run:
+        device = None
+        slots = [DryRunner() for _ in range(S)]
+        sync = lambda: None  # noqa: E731
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+        if world > torch.cuda.device_count():
+            raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
+        weights = Weights(device, cfg["precision"])
+        base = Runner(device, weights, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], golden_seed=GOLDEN_SEEDS.get(cfg["golden"]))
+        slots = [Runner(device, weights, base.shared_inputs, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], own_stream=True) for _ in range(S)]
+        sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
+    sync()
 
-    # ---- timed region: K steps, frame i on in-flight slot i % S (independent frames, no data-path collective)
+    def timed_pass(active):
+        """EXACTLY K steps, frame i on in-flight slot i % S, bracketed by barrier + synchronize on both sides."""
+        sync()
+        sharding.barrier()
+        sync()
+        t0 = time.perf_counter()
+        if active:
+            for i in range(K):
+                slots[i % S].step(i)
+        sync()
+        sharding.barrier()
+        return time.perf_counter() - t0
+
     for i in range(W):
         slots[i % S].step(i)
-    torch.cuda.synchronize(device)
-    sharding.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for i in range(K):
-        slots[i % S].step(i)
-    torch.cuda.synchronize(device)
-    sharding.barrier()
-    elapsed = time.perf_counter() - t0
+    # reference pass: rank 0 alone (the other ranks idle between the barriers) -> the fps_1 of scaling_efficiency
+    solo = timed_pass(rank == 0) if world > 1 else None
+    reps = [timed_pass(True) for _ in range(R)]
+    elapsed = float(np.median(reps))
+
+    if args.dry_run:
+        per_rank = sharding.gather_metrics([K, elapsed])
+        value, seconds = sharding.aggregate_throughput(per_rank)
+        if rank == 0:
+            print(json.dumps({"metric": "query_frames_per_sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+                              "steps": K, "warmup": W, "ms_per_step": round(seconds / K * 1e3, 4), "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run",
+                              "config": {"workload": "DRY RUN: stub steps on CPU, launcher / collective plumbing only",
+                                         "per_rank_frames_per_sec": [round(float(k / t), 2) for k, t in per_rank.tolist()]}}), flush=True)
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
 
     # ---- second pass, one frame at a time on one stream: frame latency, and the dominant kernel bracketed by
     #      HIP events recorded on that stream around one of its launches in every step
@@ -553,12 +678,15 @@ def main():
             e1.record(runner.stream)
         for i in range(W):
             runner.step(i)
-        torch.cuda.synchronize(device)
-        t1 = time.perf_counter()
-        for i in range(K):
-            runner.step_profiled(i, args.kernel, events[i][0], events[i][1])
-        torch.cuda.synchronize(device)
-        latency = (time.perf_counter() - t1) / K
+        lat = []
+        for _ in range(R):
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for i in range(K):
+                runner.step_profiled(i, args.kernel, events[i][0], events[i][1])
+            torch.cuda.synchronize(device)
+            lat.append((time.perf_counter() - t1) / K)
+        latency = float(np.median(lat))
         # calibration: the same event pair with nothing between them (the two record packets' own latency is part of
         # every bracket and is not kernel time -- rocprofv3's dispatch durations do not contain it)
         cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
@@ -567,9 +695,8 @@ def main():
             c0.record(runner.stream)
             c1.record(runner.stream)
         torch.cuda.synchronize(device)
-    kern_raw_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))   # conservative: contains part of the event packets' latency
     pair_ms = float(np.median([c0.elapsed_time(c1) for c0, c1 in cal]))
-    kern_ms = kern_raw_ms  # conservative: the bracket contains part of the event packets' own latency (pair_ms is its upper bound)
 
     amortised = None
     if args.amortised:
@@ -584,7 +711,7 @@ def main():
         for i in range(K):
             slots[i % S].step_cached(i)
         torch.cuda.synchronize(device)
-        thr = K / (time.perf_counter() - ta)
+        thr = K * runner.b / (time.perf_counter() - ta)
         ta = time.perf_counter()
         for i in range(K):
             runner.step_cached(i)
@@ -592,46 +719,61 @@ def main():
         amortised = {"frames_per_sec": round(thr, 2), "single_frame_latency_ms": round((time.perf_counter() - ta) / K * 1e3, 4),
                      "note": "3D database resident, its query-independent GNN work cached once per object; bit-identical outputs"}
 
-    per_rank = sharding.gather_metrics([K * runner.b, elapsed], device=device)  # the one (RCCL) collective
+    parity = golden_parity(runner, cfg) if rank == 0 else None
+    per_rank = sharding.gather_metrics([K * runner.b, elapsed, solo if solo is not None else elapsed], device=device)  # the one (RCCL) collective
     value, seconds = sharding.aggregate_throughput(per_rank.cpu())
 
     if rank == 0:
-        fl = kernel_flops(args.kernel, N1, N2)
+        n1, n2, bsz = cfg["n1"], cfg["n2"], runner.b
+        split = cfg["precision"] == "bf16x3" and args.kernel in ("mlp0", "qkv_kv", "mlp3")
+        fl = kernel_flops(args.kernel, n1, n2) * bsz
         achieved = fl / (kern_ms * 1e-3) / 1e12
-        # opt-in split-bf16 build knob (never the headline): the timed kernel issues 3 bf16 MFMA products per algorithmic
-        # flop, so its roofline is priced on executed flops against the bf16 peak
-        split = (os.environ.get("GATSSPG_PREC") == "bf16x3" and args.kernel in ("mlp0", "qkv_kv", "mlp3")) or \
-            os.environ.get(f"GATSSPG_{args.kernel.upper().split('_')[0]}_PREC") == "bf16x3"
         peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        if split:
+        if split:                 # 3 bf16 MFMA products are issued per algorithmic flop: price the executed flops against the bf16 peak
             achieved *= 3
+        falg = f_alg(n1, n2, NUM_LEAF)
+        per = per_rank.cpu().tolist()
+        fps1 = K * bsz / per[0][2] if world > 1 else value
         out = {
             "metric": "query_frames_per_sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": round(seconds / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic unit-norm desc_2d/desc_3d, N_2D=1000 N_3D=7000 d=256 "
-                                   "num_leaf=8, batch=1 per step, fp32, random-init GATsSPG weights (12 GNN layers)",
-                       "gemm_precision": "bf16x3 split MFMA in mlp0 / qkv_kv / mlp3 (opt-in knob, not the headline configuration)"
-                       if os.environ.get("GATSSPG_PREC") == "bf16x3" else "f32 MFMA (exact)",
-                       "n_2d": N1, "n_3d": N2, "num_leaf": NUM_LEAF, "batch": runner.b, "frames_per_gpu": K,
-                       "frames_in_flight_per_gpu": S, "single_frame_latency_ms": round(latency * 1e3, 4),
-                       "single_stream_frames_per_sec": round(1.0 / latency, 2),
-                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
-                       "algorithmic_gflop_per_frame": round(f_alg(N1, N2, NUM_LEAF) / 1e9, 2),
-                       "end_to_end_f32_mfma_frac": round(f_alg(N1, N2, NUM_LEAF) * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+            "vs_baseline": None, "dtype": "f32" if cfg["precision"] == "fp32" else "bf16x3", "data": "synthetic",
+            "config": {"workload": cfg["what"], "name": args.config,
+                       "gemm_precision": "f32 MFMA (exact)" if cfg["precision"] == "fp32" else
+                       "split-bf16 MFMA (bf16x3) in qkv_kv / mlp0 / mlp3 via GATSSPG_FLAG_PREC_BF16X3; final_proj, score, GATs fp32",
+                       "n_2d": n1, "n_3d": n2, "num_leaf": NUM_LEAF, "batch": bsz, "steps_per_gpu": K, "frames_per_gpu": K * bsz,
+                       "frames_in_flight_per_gpu": S * bsz, "timed_pass_repetitions": R,
+                       "timed_pass_seconds": [round(t, 5) for t in reps], "reported": "median repetition",
+                       "single_frame_latency_ms": round(latency * 1e3 / bsz, 4),
+                       "single_stream_frames_per_sec": round(bsz / latency, 2),
+                       "parallelism": f"weak scaling: every one of the {world} rank(s) runs its own {K} steps on its own GPU, weights and "
+                                      "database replicated, no data-path collective (one barrier pair + one metrics all_gather)",
+                       "per_rank_frames_per_sec": [round(k / t, 2) for k, t, _ in per],
+                       "algorithmic_gflop_per_frame": round(falg / 1e9, 2),
+                       "end_to_end_f32_mfma_frac": round(falg * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                       "end_to_end_single_stream_f32_mfma_frac": round(falg * bsz / latency / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "kernel": args.kernel + "_kernel", "achieved": round(achieved, 2),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": pmc_traffic(args.kernel), "kernel_ms": round(kern_ms, 5),
-                         "empty_event_pair_ms": round(pair_ms, 5),
-                         "flops_per_launch": fl,
+                         "traffic": pmc_traffic(args.kernel) if args.config == "headline" else None,
+                         "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 PMC passes of this build committed under "
+                                           "profiles/, not measured in this run)" if args.config == "headline" else None,
+                         "kernel_ms": round(kern_ms, 5), "empty_event_pair_ms": round(pair_ms, 5), "flops_per_launch": fl,
                          "how": f"hipEvent pair on the compute stream around launch #0 of {args.kernel}_kernel in each of {K} "
-                                f"steps of a one-frame-at-a-time pass (the throughput pass overlaps {S} frames); the bracket includes "
+                                f"steps of a one-frame-at-a-time pass (the throughput pass overlaps {S} steps); the bracket includes "
                                 f"event-packet latency (an empty pair on the same stream reads empty_event_pair_ms), so rocprofv3's "
                                 f"dispatch duration in profiles/ is a few us shorter"},
         }
+        if world > 1:
+            out["config"]["single_gpu_reference_frames_per_sec"] = round(fps1, 2)
+            out["config"]["scaling_efficiency"] = round(value / (world * fps1), 4)
+            out["config"]["scaling_efficiency_how"] = "value / (n_gpus * fps_1), fps_1 = the same K-step pass run by rank 0 alone while the other ranks idle"
+        if args.tuning_lib:
+            out["config"]["tuning_build"] = {k: v for k, v in os.environ.items() if k.startswith(("GATSSPG_", "SPP_"))}
+        if parity:
+            out["parity_check"] = parity
         if amortised:
             out["amortised_database_mode"] = amortised
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "headline":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():

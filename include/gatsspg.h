@@ -39,6 +39,14 @@ extern "C" {
 #define GATSSPG_FLAG_INCLUDE_SELF 1
 #define GATSSPG_FLAG_ADDITIONAL 2
 #define GATSSPG_FLAG_WITH_LINEAR_TRANSFORM 4
+/* Arithmetic of the three big GEMMs of every attention layer (QKV projection, merge+mlp.0, mlp.3), selected PER CALL --
+ * the library never reads the environment:
+ *   bit clear (default): exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's arithmetic (GATs_SuperGlue.py:191-193);
+ *   GATSSPG_FLAG_PREC_BF16X3: split-bf16 -- every fp32 operand is a sum of two bf16 terms and each product three
+ *     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE configs[2] "bf16 MFMA").  Measured against the fp32
+ *     forward: conf within 1e-6, match indices identical (tests/test_hip_parity.py runs its golden cases under both).
+ * final_proj, the score contraction, GATs and all reductions are fp32 in both modes. */
+#define GATSSPG_FLAG_PREC_BF16X3 0x100
 /* layer kinds for gatsspg_attn_layer (GATs_SuperGlue.py:55-64) */
 #define GATSSPG_LAYER_SELF 0
 #define GATSSPG_LAYER_CROSS 1
@@ -77,7 +85,8 @@ size_t gatsspg_workspace_bytes(int b, int n1, int n2, int num_leaf);
 
 /* One-time weight preparation (replaces nothing in the reference; it is what
  * load_state_dict + .cuda() is to it).  Re-orders the q/k/v projection rows head-major, folds
- * merge into mlp.0 (W0[:,256:] @ Wm), folds W @ a[:256], W @ a[256:] of each GATs layer. */
+ * merge into mlp.0 (W0[:,256:] @ Wm), folds W @ a[:256], W @ a[256:] of each GATs layer, and appends the bf16 hi/lo
+ * planes of the three big operators of every attention layer (used by GATSSPG_FLAG_PREC_BF16X3 calls). */
 int gatsspg_pack_weights(const gatsspg_raw_weights* raw, float* packed, void* stream);
 
 /* Whole forward: GATsSuperGlue.forward, GATs_SuperGlue.py:179-241, for all b samples.
@@ -92,8 +101,9 @@ int gatsspg_forward(const float* packed, const float* desc2d_query, const float*
 
 /* Same forward, with a HIP-event bracket (hipEvent_t, created by the caller, recorded on `stream`)
  * around the `occurrence`-th launch of one kernel -- how bench.py times the dominant kernel live.
- * kernel_id: 0 load_state, 1 gats, 2 qkv_kv, 3 kv_final, 4 attn_apply, 5 mlp0, 6 stat_final, 7 mlp3,
- * 8 final_proj_norm, 9 score_exp, 10 softmax_sums, 11 conf_finalize, 12 match_reduce, 13 match_tail. */
+ * kernel_id: 0 load_state (only when the first GATs launch cannot fuse it), 1 gats, 2 qkv_kv, 3 kv_final, 4 attn_apply,
+ * 5 mlp0, 6 stat_final, 7 mlp3, 8 final_proj_norm, 9 score_exp, 10 conf_finalize, 11 match_tail, 12 gats_wlt,
+ * 13 softmax_stats (max-subtracting path only). */
 int gatsspg_forward_profiled(const float* packed, const float* desc2d_query, const float* desc3d_db,
                              const float* desc2d_db, int b, int n1, int n2, int num_leaf, int flags,
                              float scale_factor, float match_threshold, float* conf, int64_t* matches0,
@@ -130,13 +140,14 @@ int gatsspg_store_state(int which, float* out2d, float* out3d, int b, int n1, in
 int gatsspg_gats_layer(const float* packed, int layer, const float* desc2d_db, int b, int n1, int n2,
                        int num_leaf, int flags, void* ws, size_t ws_bytes, void* stream);
 /* one 'self' or 'cross' layer, both sides: AttentionalGNN.forward branch GATs_SuperGlue.py:55-64
- * = 2x AttentionPropagation.forward (:111-113) + residual; layer = 0..7 */
+ * = 2x AttentionPropagation.forward (:111-113) + residual; layer = 0..7; flags: only GATSSPG_FLAG_PREC_BF16X3 matters */
 int gatsspg_attn_layer(const float* packed, int layer, int kind, int b, int n1, int n2, int num_leaf,
-                       void* ws, size_t ws_bytes, void* stream);
+                       int flags, void* ws, size_t ws_bytes, void* stream);
 /* final_proj + F.normalize (GATs_SuperGlue.py:209-213) */
 int gatsspg_final_proj_norm(const float* packed, int b, int n1, int n2, int num_leaf, void* ws,
                             size_t ws_bytes, void* stream);
-/* score einsum / scale, dual softmax, mutual-NN matching (GATs_SuperGlue.py:217-237) */
+/* score einsum / scale, dual softmax, mutual-NN matching (GATs_SuperGlue.py:217-237).  Any scale_factor > 0:
+ * 1/scale_factor <= 80 takes the fused one-pass form, smaller values the max-subtracting form of torch.softmax. */
 int gatsspg_score_dual_softmax_match(int b, int n1, int n2, int num_leaf, float scale_factor,
                                      float match_threshold, float* conf, int64_t* matches0,
                                      int64_t* matches1, float* mscores0, float* mscores1, void* ws,

@@ -13,9 +13,11 @@ from .build_ext import LIB_PATH
 
 NUM_GATS, NUM_ATTN = 4, 8
 FLAG_INCLUDE_SELF, FLAG_ADDITIONAL, FLAG_WITH_LINEAR_TRANSFORM = 1, 2, 4
+FLAG_PREC_BF16X3 = 0x100
+PRECISIONS = {"fp32": 0, "bf16x3": FLAG_PREC_BF16X3}   # GEMM arithmetic of the attention layers, selected per call
 KERNEL_IDS = {"load_state": 0, "gats": 1, "qkv_kv": 2, "kv_final": 3, "attn_apply": 4, "mlp0": 5, "stat_final": 6,
-              "mlp3": 7, "final_proj_norm": 8, "score_exp": 9, "softmax_sums": 10, "conf_finalize": 11,
-              "match_reduce": 12, "match_tail": 13}
+              "mlp3": 7, "final_proj_norm": 8, "score_exp": 9, "conf_finalize": 10, "match_tail": 11, "gats_wlt": 12,
+              "softmax_stats": 13}
 LAYER_SELF, LAYER_CROSS = 0, 1
 
 
@@ -58,7 +60,7 @@ SYMBOLS = {
     "gatsspg_store_state": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "gatsspg_gats_layer": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                    c_void_p]),
-    "gatsspg_attn_layer": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "gatsspg_attn_layer": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "gatsspg_final_proj_norm": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "gatsspg_score_dual_softmax_match": (c_int, [c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

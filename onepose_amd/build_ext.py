@@ -1,7 +1,12 @@
 """Build libgatsspg_hip.so (matcher), libspp_hip.so (SuperPoint extractor) and libpnp_hip.so (RANSAC-EPnP) in-tree with hipcc for gfx950
 (cross-compiles without a GPU).
 
-    python -m onepose_amd.build_ext [--force] [--remarks] [--profiling]
+    python -m onepose_amd.build_ext [--force] [--remarks] [--profiling] [--tuning]
+
+The product libraries never read the environment.  ``--tuning`` builds SEPARATE libraries (``lib*_tuning.so``, never
+loaded by the package) with -DGATSSPG_TUNING / -DSPP_TUNING, whose alternative tile shapes are selected by
+GATSSPG_<KNOB> / SPP_<KNOB> environment variables (tools/ab_tuning.py); ``--profiling`` adds the timing-only ablation
+variants and the mlp0 timeline hook (tools/trace_mlp0.py) to such a separate library as well.
 """
 from __future__ import annotations
 
@@ -42,18 +47,29 @@ def is_stale():
             or _stale(PNP_LIB_PATH, PNP_SOURCES + PNP_HEADERS))
 
 
-def build(force=False, remarks=False, verbose=True, profiling=False):
-    """Compile every HIP source for gfx950 into onepose_amd/lib/libgatsspg_hip.so.
-    profiling=True adds -DGATSSPG_PROFILING_BUILD (timing-only ablation variants + the mlp0 timeline hook used by
-    tools/trace_mlp0.py); never ship that build."""
+def tuning_path(lib):
+    return lib[:-3] + "_tuning.so"
+
+
+def build(force=False, remarks=False, verbose=True, profiling=False, tuning=False, syntax_only=False):
+    """Compile every HIP source for gfx950 into onepose_amd/lib/lib{gatsspg,spp,pnp}_hip.so.
+    tuning / profiling builds go to lib*_tuning.so (environment knobs; profiling adds -DGATSSPG_PROFILING_BUILD: timing-only
+    ablation variants + the mlp0 timeline hook) -- the package never loads those.  syntax_only: front-end check only."""
     os.makedirs(LIB_DIR, exist_ok=True)
+    special = tuning or profiling
     for lib, srcs, deps in ((LIB_PATH, SOURCES, SOURCES + HEADERS), (SPP_LIB_PATH, SPP_SOURCES, SPP_SOURCES + SPP_HEADERS),
                             (PNP_LIB_PATH, PNP_SOURCES, PNP_SOURCES + PNP_HEADERS)):
-        if not force and not profiling and not _stale(lib, deps):
+        if special and lib == PNP_LIB_PATH:
             continue
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", lib]
+        out = tuning_path(lib) if special else lib
+        if not force and not syntax_only and not _stale(out, deps):
+            continue
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+        cmd += ["-fsyntax-only"] if syntax_only else ["-shared", "-o", out]
         if remarks:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
+        if special:
+            cmd += ["-DGATSSPG_TUNING", "-DSPP_TUNING"]
         if profiling:
             cmd.append("-DGATSSPG_PROFILING_BUILD")
         cmd += [os.path.join(CSRC, s) for s in srcs]
@@ -64,4 +80,5 @@ def build(force=False, remarks=False, verbose=True, profiling=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, remarks="--remarks" in sys.argv, profiling="--profiling" in sys.argv)
+    build(force="--force" in sys.argv, remarks="--remarks" in sys.argv, profiling="--profiling" in sys.argv,
+          tuning="--tuning" in sys.argv)

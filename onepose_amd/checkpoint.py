@@ -61,8 +61,14 @@ class _TolerantPickle:
 def _plain(x):
     """omegaconf / stub containers -> plain python."""
     if isinstance(x, _Stub):
+        if "_val" in x and "_content" not in x:      # omegaconf value node (AnyNode / BooleanNode / FloatNode ...)
+            return _plain(x["_val"])
         inner = x.get("_content", x.get("_state", x))
-        return _plain(dict(inner)) if isinstance(inner, dict) and inner is not x else {k: _plain(v) for k, v in x.items()}
+        if inner is not x and isinstance(inner, dict):
+            return _plain(inner if isinstance(inner, _Stub) else dict(inner))
+        if isinstance(inner, (list, tuple)):         # omegaconf ListConfig
+            return [_plain(v) for v in inner]
+        return {k: _plain(v) for k, v in x.items()}
     if isinstance(x, dict):
         return {k: _plain(v) for k, v in x.items()}
     if isinstance(x, (list, tuple)):
@@ -85,8 +91,12 @@ def read_checkpoint(path, map_location="cpu"):
     raw = _plain(ckpt.get("hyper_parameters", {})) if isinstance(ckpt, dict) else {}
     if isinstance(raw, dict):
         for k in DEFAULT_HPARAMS:
-            if k in raw and not isinstance(raw[k], dict):
-                hp[k] = raw[k]
+            if k not in raw:
+                continue
+            if isinstance(raw[k], dict):   # a container that could not be decoded: never fall back silently
+                raise ValueError(f"checkpoint hyper-parameter '{k}' could not be decoded ({type(raw[k]).__name__} with keys "
+                                 f"{sorted(raw[k])[:6]}); pass it explicitly: load_from_checkpoint(path, {k}=...)")
+            hp[k] = raw[k]
     return matcher, hp
 
 

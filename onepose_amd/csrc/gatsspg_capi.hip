@@ -33,24 +33,28 @@ int check_dims(int b, int n1, int n2, int num_leaf) {
     return 0;
 }
 
-int check_ws(const void* ws, size_t ws_bytes, int b, int n1, int n2, int num_leaf, Workspace& w) {
+int check_ws(const void* ws, size_t ws_bytes, int b, int n1, int n2, int num_leaf, Workspace& w, int flags = 0) {
     if (int e = check_dims(b, n1, n2, num_leaf)) return e;
     if (!ws) return fail("workspace pointer is null");
     if (reinterpret_cast<uintptr_t>(ws) & 15) return fail("workspace must be 16-byte aligned");
+    if (flags & ~(GATSSPG_FLAG_INCLUDE_SELF | GATSSPG_FLAG_ADDITIONAL | GATSSPG_FLAG_WITH_LINEAR_TRANSFORM | GATSSPG_FLAG_PREC_BF16X3))
+        return fail("unknown bits in flags (0x%x)", flags);
     w = carve_workspace(const_cast<void*>(ws), b, n1, n2);
+    w.prec = (flags & GATSSPG_FLAG_PREC_BF16X3) ? 1 : 0;
     if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu bytes", ws_bytes, w.bytes);
     return 0;
 }
 
-// The dual softmax is evaluated without max-subtraction: the scores are cosines / scale_factor, so exp() stays in range
-// as long as 1 / scale_factor <= 80 (exp(80) = 5.5e34, row sums of 1e5 terms still fit fp32).  The reference's 0.07 gives
-// 14.3.  Smaller scale factors are refused rather than silently overflowing.
+// The dual softmax is evaluated without max-subtraction whenever that is safe: the scores are cosines / scale_factor, so
+// exp() stays in range as long as 1 / scale_factor <= 80 (exp(80) = 5.5e34, row sums of 1e5 terms still fit fp32; the
+// reference's 0.07 gives 14.3) and one pass over S yields both normalisers.  Smaller scale factors take the
+// max-subtracting path (raw scores -> row/column maxima and shifted sums -> finalize), which has the full range of
+// torch.softmax (GATs_SuperGlue.py:218).
 int check_scale(float scale_factor) {
     if (!(scale_factor > 0.f)) return fail("scale_factor must be positive");
-    if (scale_factor < 0.0125f)
-        return fail("scale_factor %g is below 0.0125: exp(1/scale_factor) would overflow the fused fp32 dual softmax", scale_factor);
     return 0;
 }
+inline int softmax_shifted(float scale_factor) { return scale_factor < 0.0125f ? 1 : 0; }
 
 int check_launch(const char* what) {
     const hipError_t e = hipGetLastError();
@@ -59,10 +63,14 @@ int check_launch(const char* what) {
 }
 
 const float* attn_w(const float* packed, int layer) { return packed + PW_ATTN + (size_t)layer * AttnW::SIZE; }
+const unsigned short* attn_wb(const float* packed, int layer) {
+    return reinterpret_cast<const unsigned short*>(packed + PW_TOTAL) + (size_t)layer * AttnWB::SIZE;
+}
 const float* gats_w(const float* packed, int layer) { return packed + PW_GATS + (size_t)layer * GatsW::SIZE; }
 
+// h3 / dq: fused state load (see launch_gats); only valid when gats_fuses_state_load() says so
 void enqueue_gats(const float* packed, int layer, const float* desc2d_db, int num_leaf, int flags, const Workspace& w,
-                  hipStream_t s, ProfileHook* hk = nullptr) {
+                  hipStream_t s, ProfileHook* hk = nullptr, const float* h3 = nullptr, const float* dq = nullptr) {
     const float* g = gats_w(packed, layer);
     if (flags & GATSSPG_FLAG_WITH_LINEAR_TRANSFORM) {
         // pre-activation aggregate -> MSG (free between attention layers), then elu(W^T pre (+h))
@@ -70,15 +78,16 @@ void enqueue_gats(const float* packed, int layer, const float* desc2d_db, int nu
         const int add_h = (flags & GATSSPG_FLAG_INCLUDE_SELF) && (flags & GATSSPG_FLAG_ADDITIONAL);
         launch_gats_wlt(g + GatsW::W, w.MSG, w, add_h, s, hk);
     } else {
-        launch_gats(g + GatsW::U1, g + GatsW::U2, desc2d_db, num_leaf, flags, w.Z, w, s, hk);
+        launch_gats(g + GatsW::U1, g + GatsW::U2, desc2d_db, num_leaf, flags, w.Z, w, s, hk, h3, dq);
     }
 }
 
 void enqueue_attn(const float* packed, int layer, int kind, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr) {
     const float* a = attn_w(packed, layer);
-    launch_qkv_kv(a + AttnW::WQKV, a + AttnW::BQKV, w, s, hk);
+    const unsigned short* ab = attn_wb(packed, layer);
+    launch_qkv_kv(a + AttnW::WQKV, a + AttnW::BQKV, ab, w, s, hk);
     launch_attn_apply(w, kind == GATSSPG_LAYER_CROSS, s, hk);
-    launch_mlp(a + AttnW::W0, a + AttnW::B0, a + AttnW::W3, a + AttnW::B3, w, s, hk);
+    launch_mlp(a + AttnW::W0, a + AttnW::B0, a + AttnW::W3, a + AttnW::B3, ab, w, s, hk);
 }
 
 // ---- database cache: everything of the first three GNN layers that depends only on the
@@ -108,30 +117,34 @@ int forward_impl(const float* packed, const float* desc2d_query, const float* de
                  int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, void* ws, size_t ws_bytes,
                  void* stream, ProfileHook* hk) {
     Workspace w;
-    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
+    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w, flags)) return e;
     if (!packed || !desc2d_query || !desc3d_db || !desc2d_db) return fail("null input pointer");
     if (!conf || !matches0 || !matches1 || !mscores0 || !mscores1) return fail("null output pointer");
     if (int e = check_scale(scale_factor)) return e;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    launch_load_state(desc2d_query, desc3d_db, w, s, hk);
+    // the state load is fused into the first GATs launch where that kernel supports it (num_leaf == 8, no linear transform)
+    const bool fused_load = gats_fuses_state_load(num_leaf, flags, w);
+    if (!fused_load) launch_load_state(desc2d_query, desc3d_db, w, s, hk);
     for (int t = 0; t < 4; ++t) {  // ['GATs', 'self', 'cross'] * 4, GATs_SuperGlue.py:162
-        enqueue_gats(packed, t, desc2d_db, num_leaf, flags, w, s, hk);
+        if (t == 0 && fused_load) enqueue_gats(packed, t, desc2d_db, num_leaf, flags, w, s, hk, desc3d_db, desc2d_query);
+        else enqueue_gats(packed, t, desc2d_db, num_leaf, flags, w, s, hk);
         enqueue_attn(packed, 2 * t, GATSSPG_LAYER_SELF, w, s, hk);
         enqueue_attn(packed, 2 * t + 1, GATSSPG_LAYER_CROSS, w, s, hk);
     }
+    const int shifted = softmax_shifted(scale_factor);
     launch_final_proj_norm(packed + PW_FINAL_W, packed + PW_FINAL_B, w, s, hk);
-    launch_score_exp(w, conf, scale_factor, s, hk);
-    launch_dual_softmax_match(w, conf, match_threshold, matches0, matches1, mscores0, mscores1, s, hk);
+    launch_score_exp(w, conf, scale_factor, shifted, s, hk);
+    launch_dual_softmax_match(w, conf, scale_factor, shifted, match_threshold, matches0, matches1, mscores0, mscores1, s, hk);
     return check_launch("forward");
 }
 }  // namespace
 
 extern "C" {
 
-int gatsspg_version(void) { return 100; }
+int gatsspg_version(void) { return 200; }
 const char* gatsspg_last_error(void) { return g_err; }
 
-size_t gatsspg_packed_weights_bytes(void) { return sizeof(float) * PW_TOTAL; }
+size_t gatsspg_packed_weights_bytes(void) { return PACKED_BYTES; }
 
 size_t gatsspg_workspace_bytes(int b, int n1, int n2, int num_leaf) {
     if (check_dims(b, n1, n2, num_leaf)) return 0;
@@ -143,7 +156,9 @@ int gatsspg_pack_weights(const gatsspg_raw_weights* raw, float* packed, void* st
     const void* const* p = reinterpret_cast<const void* const*>(raw);
     for (size_t i = 0; i < sizeof(gatsspg_raw_weights) / sizeof(void*); ++i)
         if (!p[i]) return fail("raw weight pointer #%zu is null", i);
+    if (reinterpret_cast<uintptr_t>(packed) & 15) return fail("packed-weights buffer must be 16-byte aligned");
     launch_pack_weights(raw, packed, static_cast<hipStream_t>(stream));
+    launch_split_weights(packed, reinterpret_cast<unsigned short*>(packed + PW_TOTAL), static_cast<hipStream_t>(stream));
     return check_launch("pack_weights");
 }
 
@@ -169,17 +184,17 @@ int gatsspg_store_state(int which, float* out2d, float* out3d, int b, int n1, in
 int gatsspg_gats_layer(const float* packed, int layer, const float* desc2d_db, int b, int n1, int n2, int num_leaf,
                        int flags, void* ws, size_t ws_bytes, void* stream) {
     Workspace w;
-    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
+    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w, flags)) return e;
     if (!packed || !desc2d_db) return fail("null argument");
     if (layer < 0 || layer >= GATSSPG_NUM_GATS_LAYERS) return fail("GATs layer index %d out of range", layer);
     enqueue_gats(packed, layer, desc2d_db, num_leaf, flags, w, static_cast<hipStream_t>(stream));
     return check_launch("gats_layer");
 }
 
-int gatsspg_attn_layer(const float* packed, int layer, int kind, int b, int n1, int n2, int num_leaf, void* ws,
+int gatsspg_attn_layer(const float* packed, int layer, int kind, int b, int n1, int n2, int num_leaf, int flags, void* ws,
                        size_t ws_bytes, void* stream) {
     Workspace w;
-    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
+    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w, flags)) return e;
     if (!packed) return fail("null argument");
     if (layer < 0 || layer >= GATSSPG_NUM_ATTN_LAYERS) return fail("attention layer index %d out of range", layer);
     if (kind != GATSSPG_LAYER_SELF && kind != GATSSPG_LAYER_CROSS) return fail("kind must be SELF or CROSS");
@@ -204,8 +219,9 @@ int gatsspg_score_dual_softmax_match(int b, int n1, int n2, int num_leaf, float 
     if (!conf || !matches0 || !matches1 || !mscores0 || !mscores1) return fail("null output pointer");
     if (int e = check_scale(scale_factor)) return e;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    launch_score_exp(w, conf, scale_factor, s);
-    launch_dual_softmax_match(w, conf, match_threshold, matches0, matches1, mscores0, mscores1, s);
+    const int shifted = softmax_shifted(scale_factor);
+    launch_score_exp(w, conf, scale_factor, shifted, s);
+    launch_dual_softmax_match(w, conf, scale_factor, shifted, match_threshold, matches0, matches1, mscores0, mscores1, s);
     return check_launch("score_dual_softmax_match");
 }
 
@@ -251,7 +267,7 @@ int gatsspg_prepare_database(const float* packed, const float* desc3d_db, const 
                              int num_leaf, int flags, void* cache, size_t cache_bytes, void* ws, size_t ws_bytes,
                              void* stream) {
     Workspace w;
-    if (int e = check_ws(ws, ws_bytes, b, 2, n2, num_leaf, w)) return e;   // 2 dummy (zero) query columns
+    if (int e = check_ws(ws, ws_bytes, b, 2, n2, num_leaf, w, flags)) return e;   // 2 dummy (zero) query columns
     if (!packed || !desc3d_db || !desc2d_db || !cache) return fail("null argument");
     const DbCache c = carve_cache(cache, b, n2);
     if (cache_bytes < c.bytes) return fail("database cache too small: %zu < %zu bytes", cache_bytes, c.bytes);
@@ -261,7 +277,7 @@ int gatsspg_prepare_database(const float* packed, const float* desc3d_db, const 
     enqueue_gats(packed, 0, desc2d_db, num_leaf, flags, w, s);              // gnn.layers.0 (3D side only by nature)
     enqueue_attn(packed, 0, GATSSPG_LAYER_SELF, wy, s);                     // gnn.layers.1, 3D side
     const float* a1 = attn_w(packed, 1);
-    launch_qkv_kv(a1 + AttnW::WQKV, a1 + AttnW::BQKV, wy, s);               // gnn.layers.2: 3D-side Q, KV, ksum
+    launch_qkv_kv(a1 + AttnW::WQKV, a1 + AttnW::BQKV, attn_wb(packed, 1), wy, s);   // gnn.layers.2: 3D-side Q, KV, ksum
     launch_store_state(w.Z, nullptr, c.Y2, w, s);
     launch_store_state(w.Q, nullptr, c.QY, w, s);
     if (hipMemcpy2DAsync(c.kvY, sizeof(float) * H * KVP, w.kvfin + (size_t)H * KVP, sizeof(float) * 2 * H * KVP,
@@ -275,7 +291,7 @@ int gatsspg_forward_cached(const float* packed, const float* desc2d_query, const
                            float match_threshold, float* conf, int64_t* matches0, int64_t* matches1, float* mscores0,
                            float* mscores1, void* ws, size_t ws_bytes, void* stream) {
     Workspace w;
-    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w)) return e;
+    if (int e = check_ws(ws, ws_bytes, b, n1, n2, num_leaf, w, flags)) return e;
     if (!packed || !desc2d_query || !desc2d_db || !cache) return fail("null input pointer");
     if (!conf || !matches0 || !matches1 || !mscores0 || !mscores1) return fail("null output pointer");
     if (int e = check_scale(scale_factor)) return e;
@@ -286,21 +302,22 @@ int gatsspg_forward_cached(const float* packed, const float* desc2d_query, const
     launch_load_state(desc2d_query, c.Y2, w, s);                            // state = [X0 | cached Y2]
     enqueue_attn(packed, 0, GATSSPG_LAYER_SELF, wx, s);                     // gnn.layers.1, query side only
     const float* a1 = attn_w(packed, 1);
-    launch_qkv_kv(a1 + AttnW::WQKV, a1 + AttnW::BQKV, wx, s);               // gnn.layers.2: query-side Q, KV, ksum
+    launch_qkv_kv(a1 + AttnW::WQKV, a1 + AttnW::BQKV, attn_wb(packed, 1), wx, s);   // gnn.layers.2: query-side Q, KV, ksum
     launch_load_columns(nullptr, c.QY, w.Q, w, s);                          // 3D-side Q and KV sums from the cache
     if (hipMemcpy2DAsync(w.kvfin + (size_t)H * KVP, sizeof(float) * 2 * H * KVP, c.kvY, sizeof(float) * H * KVP,
                          sizeof(float) * H * KVP, b, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return fail("forward_cached: copy of the KV sums failed");
     launch_attn_apply(w, 1, s);
-    launch_mlp(a1 + AttnW::W0, a1 + AttnW::B0, a1 + AttnW::W3, a1 + AttnW::B3, w, s);
+    launch_mlp(a1 + AttnW::W0, a1 + AttnW::B0, a1 + AttnW::W3, a1 + AttnW::B3, attn_wb(packed, 1), w, s);
     for (int t = 1; t < 4; ++t) {
         enqueue_gats(packed, t, desc2d_db, num_leaf, flags, w, s);
         enqueue_attn(packed, 2 * t, GATSSPG_LAYER_SELF, w, s);
         enqueue_attn(packed, 2 * t + 1, GATSSPG_LAYER_CROSS, w, s);
     }
+    const int shifted = softmax_shifted(scale_factor);
     launch_final_proj_norm(packed + PW_FINAL_W, packed + PW_FINAL_B, w, s);
-    launch_score_exp(w, conf, scale_factor, s);
-    launch_dual_softmax_match(w, conf, match_threshold, matches0, matches1, mscores0, mscores1, s);
+    launch_score_exp(w, conf, scale_factor, shifted, s);
+    launch_dual_softmax_match(w, conf, scale_factor, shifted, match_threshold, matches0, matches1, mscores0, mscores1, s);
     return check_launch("forward_cached");
 }
 

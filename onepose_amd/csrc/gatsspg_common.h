@@ -19,7 +19,7 @@ constexpr int QKV_BN = 64;    // column tile of the QKV+KV-partial kernel (one K
 constexpr int MLP0_BN = 64;   // column tile of the mlp.0 kernel (one InstanceNorm partial per tile)
 constexpr int SC_BM = 128;    // score kernel row tile (over n1)
 constexpr int SC_BN = 64;     // score kernel column tile (over n2)
-constexpr int CF_ROWS = 8;    // conf-finalize strip height (all rows of a strip are loaded at once)
+constexpr int CF_ROWS = 16;   // conf-finalize strip height: 4 waves x 4 rows, all loaded before any is processed
 constexpr int CF_COLS = 1024; // conf-finalize chunk width
 
 // Activation state: channel-major [channels][ld] fp32; frame f owns columns [f*np, (f+1)*np):
@@ -93,20 +93,37 @@ constexpr size_t PW_ATTN = 0;
 constexpr size_t PW_GATS = PW_ATTN + 8 * AttnW::SIZE;
 constexpr size_t PW_FINAL_W = PW_GATS + 4 * GatsW::SIZE;
 constexpr size_t PW_FINAL_B = PW_FINAL_W + 256 * 256;
-constexpr size_t PW_TOTAL = PW_FINAL_B + 256;
+constexpr size_t PW_TOTAL = PW_FINAL_B + 256;   // floats
+
+// Split-bf16 planes of the three big GEMM operators (GATSSPG_FLAG_PREC_BF16X3): appended to the fp32 blob, in bf16
+// elements from (unsigned short*)(packed + PW_TOTAL).  w = hi + lo with hi = RNE_bf16(w), lo = RNE_bf16(w - hi);
+// same row order as the fp32 matrices they are split from.
+struct AttnWB {
+    static constexpr size_t QKV_HI = 0;                          // [768][256]
+    static constexpr size_t QKV_LO = QKV_HI + 768 * 256;
+    static constexpr size_t W0_HI = QKV_LO + 768 * 256;          // [512][512]
+    static constexpr size_t W0_LO = W0_HI + 512 * 512;
+    static constexpr size_t W3_HI = W0_LO + 512 * 512;           // [256][512]
+    static constexpr size_t W3_LO = W3_HI + 256 * 512;
+    static constexpr size_t SIZE = W3_LO + 256 * 512;
+};
+constexpr size_t PWB_TOTAL = 8 * AttnWB::SIZE;                   // bf16 elements
+constexpr size_t PACKED_BYTES = sizeof(float) * PW_TOTAL + sizeof(unsigned short) * PWB_TOTAL;
 
 // ---- workspace carve-up ---------------------------------------------------------------------------
 struct Workspace {
     ColLayout L;
+    int prec;          // 0: exact fp32 MFMA; 1: split-bf16 (bf16x3) main loops in qkv_kv / mlp0 / mlp3 (set from the call's flags)
     int nt64;          // ld / 64 column tiles
     int nseg;          // 2*b
     int sc_nct, sc_nrt;   // score kernel tiles per frame (n2p/SC_BN, n1p/SC_BM)
     int cf_nst, cf_nch;   // conf-finalize strips / chunks per frame
-    float *Z, *Q, *MSG, *U, *MD;     // MD aliases Q (Q is dead after the GNN); T aliases MSG
+    float *Z, *Q, *MSG, *U, *MD;     // MD aliases Q (Q is dead after the GNN)
+    float *MDT;                      // query-side normalised descriptors, point-major [b][n1p][256]; aliases MSG
     float *kvpart, *kvfin, *statpart, *stats;
     float *rowpart, *colpart, *rs, *cs;
-    float *rmax_v, *cmax_v, *max0;
-    int *rmax_i, *cmax_i, *idx0, *idx1;
+    float *rmax_v, *cmax_v, *rshift, *cshift;   // rshift / cshift: row / column maxima of the max-subtracting dual softmax
+    int *rmax_i, *cmax_i;
     size_t bytes;
 };
 
@@ -115,6 +132,7 @@ inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 inline Workspace carve_workspace(void* base, int b, int n1, int n2) {
     Workspace w;
     w.L = make_layout(b, n1, n2);
+    w.prec = 0;
     const ColLayout& L = w.L;
     w.nt64 = L.ld / 64;
     w.nseg = 2 * b;
@@ -131,6 +149,7 @@ inline Workspace carve_workspace(void* base, int b, int n1, int n2) {
     w.MSG = (float*)take(sizeof(float) * D * ld);
     w.U = (float*)take(sizeof(float) * 2 * D * ld);
     w.MD = w.Q;
+    w.MDT = w.MSG;   // b * n1p * 256 floats <= 256 * ld
     w.kvpart = (float*)take(sizeof(float) * (size_t)w.nt64 * H * KVP);
     w.kvfin = (float*)take(sizeof(float) * (size_t)w.nseg * H * KVP);
     w.statpart = (float*)take(sizeof(float) * (size_t)w.nt64 * 2 * 512);
@@ -143,9 +162,8 @@ inline Workspace carve_workspace(void* base, int b, int n1, int n2) {
     w.rmax_i = (int*)take(sizeof(int) * (size_t)b * w.cf_nch * L.n1p);
     w.cmax_v = (float*)take(sizeof(float) * (size_t)b * w.cf_nst * L.n2p);
     w.cmax_i = (int*)take(sizeof(int) * (size_t)b * w.cf_nst * L.n2p);
-    w.max0 = (float*)take(sizeof(float) * (size_t)b * L.n1p);
-    w.idx0 = (int*)take(sizeof(int) * (size_t)b * L.n1p);
-    w.idx1 = (int*)take(sizeof(int) * (size_t)b * L.n2p);
+    w.rshift = (float*)take(sizeof(float) * (size_t)b * L.n1p);
+    w.cshift = (float*)take(sizeof(float) * (size_t)b * L.n2p);
     w.bytes = off;
     return w;
 }

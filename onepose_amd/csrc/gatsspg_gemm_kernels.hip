@@ -2,11 +2,8 @@
 // linear-attention KV reduction / apply, and the N_2D x N_3D score contraction.
 // Reference maths: GATs_SuperGlue.py:69-128 (linear_attention, MultiHeadedAttention,
 // AttentionPropagation, MLP) and :209-218 (final_proj, normalize, score einsum, exp of the softmax).
-#include <string.h>
-
 #include "gemm_f32_mfma.h"
 #include "gatsspg_launch.h"
-#include <stdlib.h>
 
 namespace gatsspg {
 
@@ -18,13 +15,16 @@ namespace gatsspg {
 //                    this column tile's partial  KV_h[q][d] = sum_m V[q][m] K[d][m],  ksum_h[d].
 //     (GATs_SuperGlue.py:96-99 projections, :71-72 feature map, :77-78 KV and key.sum)
 // =====================================================================================================
-using QkvTile = GemmTile<128, QKV_BN, 2, 2, false>;
-using QkvTileW8 = GemmTile<128, QKV_BN, 4, 2, false>;     // same tile on 8 waves (one 32x32 MFMA tile each)
+using QkvTileW8 = GemmTile<128, QKV_BN, 4, 2, false>;     // fp32: 8 waves, one 32x32 MFMA tile each (38.0 vs 40.1 us on 4 waves)
+using QkvTileB = GemmTile<128, QKV_BN, 2, 2, false>;      // split-bf16: 4 waves, 64x32 per wave (LDS fragment reads per MFMA 2/3)
 
+// PREC = 0: exact fp32 MFMA.  PREC = 1: split-bf16 main loop on the pre-split weight planes Whi / Wlo.
 template <class T, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS) void qkv_kv_kernel(const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
+                                                            const unsigned short* __restrict__ Whi,
+                                                            const unsigned short* __restrict__ Wlo,
                                                             const float* __restrict__ Z, float* __restrict__ Qbuf,
-                                                            float* __restrict__ kvpart, ColLayout L, int vec_store) {
+                                                            float* __restrict__ kvpart, ColLayout L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int rt, ct;
     if (!xcd_tile_map(6, active_tiles(L), rt, ct)) return;
@@ -34,31 +34,23 @@ __global__ __launch_bounds__(T::THREADS) void qkv_kv_kernel(const float* __restr
     const float* A = Wqkv + (size_t)rt * 128 * D;
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
-    if constexpr (PREC == 1)
+    if constexpr (PREC == 1) {
+        const unsigned short* Ah = Whi + (size_t)rt * 128 * D;
+        const unsigned short* Al = Wlo + (size_t)rt * 128 * D;
         gemm_mainloop_bf3<T>(
-            acc, reinterpret_cast<unsigned short*>(smem), D / BK, [&](int kt) { return A + kt * BK; }, D,
-            [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
-    else
+            acc, reinterpret_cast<unsigned short*>(smem), D / BK, [&](int kt) { return Ah + kt * BK; },
+            [&](int kt) { return Al + kt * BK; }, D, [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
+    } else {
         gemm_mainloop<T>(
             acc, smem, D / BK, [&](int kt) { return A + kt * BK; }, D,
             [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
-    if (rt < 2 && vec_store) {
+    if (rt < 2) {
         const float* bq = bqkv + rt * 128;
         store_tile_via_lds<T>(acc, smem, Qbuf + (size_t)rt * 128 * ld + c0, ld, [&](int row, float v) { return elu1(v + bq[row]) + 1.f; });
-        return;
-    }
-    if (rt < 2) {
-#pragma unroll
-        for (int tm = 0; tm < T::TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rt * 128 + (wm * T::TM + tm) * 32 + mfma_row(r, half);
-                const float v = acc[tm][0][r] + bqkv[row];
-                Qbuf[(size_t)row * ld + c0 + wn * 32 + l31] = elu1(v) + 1.f;
-            }
         return;
     }
     // ---- K_h / V_h tile -> LDS -> KV partial ----
@@ -195,12 +187,10 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
 //     (GATs_SuperGlue.py:101 merge, :113 cat, :122 first Conv1d) + per-tile InstanceNorm partials
 //     (sum u, sum u^2 over the tile's real columns; :126).
 // =====================================================================================================
-// tile variants (BN is fixed to MLP0_BN = 64: one InstanceNorm partial per 64-column tile)
-using Mlp0Tile = GemmTile<128, MLP0_BN, 2, 2, false>;
-using Mlp0TileWide = GemmTile<256, MLP0_BN, 4, 1, false>;
-using Mlp0TileW8 = GemmTile<128, MLP0_BN, 4, 2, false>;    // 8 waves, one 32x32 MFMA tile each
-using Mlp0TileBig = GemmTile<128, 2 * MLP0_BN, 2, 4, false>;   // 8 waves, 128x128: a third fewer operand bytes per MFMA
-using Mlp0TileFlat = GemmTile<64, 2 * MLP0_BN, 2, 4, false>;   // 8 waves, 64x128: weights re-read less, activations more
+// tiles (one InstanceNorm partial per 64-column tile whatever BN is)
+using Mlp0TileW8 = GemmTile<128, MLP0_BN, 4, 2, false>;       // fp32 default: 8 waves, one 32x32 MFMA tile each (43.1 vs 45.0 us on 4 waves)
+using Mlp0TileB = GemmTile<128, MLP0_BN, 2, 2, false>;        // split-bf16: 4 waves, 64x32 per wave
+using Mlp0TileB8 = GemmTile<128, 2 * MLP0_BN, 2, 4, false>;   // split-bf16 alternative (tuning builds): 128x128 on 8 waves
 
 // per-workgroup timeline of mlp0_kernel (tools/trace_mlp0.py): 8 x u64 per workgroup
 // [hw_id, xcc_id, t_entry, shader cycles, t_after_mainloop, t_end, rt, ct], 100 MHz wall clock.
@@ -211,12 +201,13 @@ unsigned long long* g_trace = nullptr;
 static constexpr unsigned long long* g_trace = nullptr;
 #endif
 
-// PREC = 0: exact fp32 MFMA (default).  PREC = 1: split-bf16 ("bf16x3") main loop, opt-in (GATSSPG_MLP0_PREC=bf16x3).
+// ABL (profiling builds only, wrong results): main-loop ablations of gemm_mainloop_ex.  PREC as in qkv_kv_kernel.
 template <class T, int ABL = 0, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
+                                                   const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
                                                    const float* __restrict__ Z, const float* __restrict__ MSG,
                                                    float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
-                                                   unsigned long long* trace, int vec_store) {
+                                                   unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned long long t_entry = trace ? wall_clock64() : 0;
     const unsigned long long c_entry = trace ? clock64() : 0;
@@ -235,8 +226,11 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
     auto al = [&](int kt) { return Ah + kt * BK; };
     auto bl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : MSG + (size_t)(kt - 8) * BK * ld) + ch0; };
     if constexpr (PREC == 1) {
-        gemm_mainloop_bf3<T>(acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, al, 512, bl, ld);
-        __syncthreads();
+        const unsigned short* Bh = Whi + (size_t)rt * T::BM * 512;
+        const unsigned short* Bl = Wlo + (size_t)rt * T::BM * 512;
+        gemm_mainloop_bf3<T>(
+            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, [&](int kt) { return Bh + kt * BK; },
+            [&](int kt) { return Bl + kt * BK; }, 512, bl, ld);
     } else {
         gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL)>(acc, smem, 512 / BK, al, 512, bl, ld);
     }
@@ -245,7 +239,7 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
     const unsigned long long t_loop = trace ? wall_clock64() : 0;
     const TileSeg ts = tile_seg(L, c0, T::BN);
     constexpr int TS = T::BN + 1;
-    float* Tl = smem;  // [BM][65]
+    float* Tl = smem;  // [BM][BN + 1]
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
@@ -254,18 +248,15 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
             for (int r = 0; r < 16; ++r) {
                 const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);
                 const int col = (wn * T::TN + tn) * 32 + l31;
-                const float v = acc[tm][tn][r] + b0[rt * T::BM + row];
-                if (!vec_store) U[(size_t)(rt * T::BM + row) * ld + c0 + col] = v;
-                Tl[row * TS + col] = v;
+                Tl[row * TS + col] = acc[tm][tn][r] + b0[rt * T::BM + row];
             }
     __syncthreads();
-    if (vec_store) {   // the tile leaves through LDS as 16-byte stores: 16 lanes cover one 256-byte row segment
-        for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
-            const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
-            const float* t = Tl + row * TS + c4;
-            vf4 v = {t[0], t[1], t[2], t[3]};
-            *reinterpret_cast<vf4*>(U + (size_t)(rt * T::BM + row) * ld + c0 + c4) = v;
-        }
+    // the tile leaves through LDS as 16-byte stores: 16 lanes cover one 256-byte row segment
+    for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
+        const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
+        const float* t = Tl + row * TS + c4;
+        vf4 v = {t[0], t[1], t[2], t[3]};
+        *reinterpret_cast<vf4*>(U + (size_t)(rt * T::BM + row) * ld + c0 + c4) = v;
     }
     {   // per-row (sum, centred sum of squares) of the real columns of each 64-column tile: THREADS / BM lanes per row,
         // each a fixed contiguous column range, combined by shuffles (fixed order).  One pass, shifted by the first
@@ -359,16 +350,15 @@ __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restric
 // K6  mlp.3 with the InstanceNorm + ReLU applied on the B-operand load; the accumulators start from
 //     residual + bias:  Z = (Z + b3) + W3 relu((u - mean) * rstd)      (GATs_SuperGlue.py:126-128, :59,64)
 // =====================================================================================================
-using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;
-using Mlp3TileTall = GemmTile<128, 64, 2, 2, false>;
-using Mlp3TileWide = GemmTile<64, 128, 1, 4, false>;
-using Mlp3TileTallW8 = GemmTile<128, 64, 4, 2, false>;   // 8 waves
-using Mlp3TileWideW8 = GemmTile<64, 128, 2, 4, false>;   // 8 waves
+using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;          // fp32 default: 64x64 on 4 waves (504 workgroups)
+using Mlp3TileTallW8 = GemmTile<128, 64, 4, 2, false>;   // fp32 alternative (tuning builds): 128x64 on 8 waves (kernel -6 %, 252 workgroups)
+using Mlp3TileB = GemmTile<128, 64, 2, 2, false>;        // split-bf16: 128x64 on 4 waves, 64x32 per wave
 
 template <class T, int ABL = 0, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
+                                                   const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
                                                    const float* __restrict__ U, const float* __restrict__ stats,
-                                                   float* __restrict__ Z, ColLayout L, int vec_store) {
+                                                   float* __restrict__ Z, ColLayout L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int rt, ct;
     constexpr int MT = 256 / T::BM;
@@ -400,43 +390,36 @@ __global__ __launch_bounds__(T::THREADS) void mlp3_kernel(const float* __restric
     auto bl = [&](int kt) { return U + (size_t)kt * BK * ld + c0; };
     auto xm = [&](int kt) { return mean + kt * BK; };
     auto xr = [&](int kt) { return rstd + kt * BK; };
-    auto bx = [](vf4& v, float2 ms) {
+    if constexpr (PREC == 1) {
+        const unsigned short* Bh = Whi + (size_t)rt * T::BM * 512;
+        const unsigned short* Bl = Wlo + (size_t)rt * T::BM * 512;
+        auto ah = [&](int kt) { return Bh + kt * BK; };
+        auto alo = [&](int kt) { return Bl + kt * BK; };
+        auto bx1 = [](float v, float2 ms) { return fmaxf((v - ms.x) * ms.y, 0.f); };
+        gemm_mainloop_bf3_ex<T, decltype(ah), decltype(alo), decltype(bl), decltype(xm), decltype(xr), decltype(bx1), true>(
+            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, ah, alo, 512, bl, ld, xm, xr, bx1);
+    } else {
+        auto bx = [](vf4& v, float2 ms) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = fmaxf((v[q] - ms.x) * ms.y, 0.f);
-    };
-    if constexpr (PREC == 1)
-        gemm_mainloop_bf3_ex<T, decltype(al), decltype(bl), decltype(xm), decltype(xr), decltype(bx), true>(
-            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, al, 512, bl, ld, xm, xr, bx);
-    else
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf((v[q] - ms.x) * ms.y, 0.f);
+        };
         gemm_mainloop_ex<T, decltype(al), decltype(bl), decltype(xm), decltype(xr), decltype(bx), true, ABL>(
             acc, smem, 512 / BK, al, 512, bl, ld, xm, xr, bx);
-    if (vec_store) {
-        store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [](int, float v) { return v; });
-        return;
     }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
-#pragma unroll
-    for (int tm = 0; tm < T::TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < T::TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rt * T::BM + (wm * T::TM + tm) * 32 + mfma_row(r, half);
-                Z[(size_t)row * ld + c0 + (wn * T::TN + tn) * 32 + l31] = acc[tm][tn][r];
-            }
+    store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [](int, float v) { return v; });
 }
 
 // =====================================================================================================
 // K7  final_proj + F.normalize(p=2, dim=channels, eps=1e-12)      (GATs_SuperGlue.py:209-213)
 //     One workgroup owns all 256 output channels of a 32-column tile, so the L2 norm is an
-//     in-block reduction.
+//     in-block reduction.  Query-side tiles additionally leave point-major (MDT [b][n1p][256], 1 KiB rows): the score
+//     GEMM then reads its A operand row-major like a weight matrix (b128 fragment reads) instead of [K][M].
 // =====================================================================================================
 using FinalTile = GemmTile<256, 32, 4, 1, false>;
 
 __global__ __launch_bounds__(256) void final_proj_norm_kernel(const float* __restrict__ Wf, const float* __restrict__ bf,
                                                               const float* __restrict__ Z, float* __restrict__ MD,
-                                                              ColLayout L) {
+                                                              float* __restrict__ MDT, ColLayout L) {
     using T = FinalTile;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float npart[4][32];
@@ -464,41 +447,53 @@ __global__ __launch_bounds__(256) void final_proj_norm_kernel(const float* __res
     __syncthreads();
     const float nrm = sqrtf((npart[0][l31] + npart[1][l31]) + (npart[2][l31] + npart[3][l31]));
     const float inv = 1.f / fmaxf(nrm, 1e-12f);
+    const TileSeg ts = tile_seg(L, c0, T::BN);   // 32-column tiles never straddle a segment (segments are multiples of 128)
+    constexpr int TS = D + 4;                    // point-major staging tile [32][260]
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wave * 64 + tm * 32 + mfma_row(r, half);
-            MD[(size_t)row * ld + c0 + l31] = acc[tm][0][r] * inv;
+            const float v = acc[tm][0][r] * inv;
+            MD[(size_t)row * ld + c0 + l31] = v;
+            if (ts.side == 0) smem[l31 * TS + row] = v;   // block-uniform branch; the main loop ended on a barrier
         }
+    if (ts.side == 0) {
+        __syncthreads();
+        float* dst = MDT + ((size_t)ts.frame * L.n1p + (c0 - ts.seg_start)) * D;
+        for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
+            const int pt = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
+            *reinterpret_cast<vf4*>(dst + (size_t)pt * D + c4) = *reinterpret_cast<const vf4*>(smem + pt * TS + c4);
+        }
+    }
 }
 
 // =====================================================================================================
-// K8  score contraction + exp:  E[n][m] = exp( (sum_d A[d][n] B[d][m]) / scale_factor )
-//     (GATs_SuperGlue.py:217 and the numerator of both softmaxes of :218; |score| <= 1/0.07 so the
-//     max-subtraction of softmax is not needed for range).  E is written into the conf buffer; the
-//     tile's row sums (over its 64 columns) and column sums (over its 128 rows) go to partial
-//     buffers that are reduced in a fixed order.
+// K8  score contraction + exp:  E[n][m] = exp( (sum_d A[n][d] B[d][m]) / scale_factor )
+//     (GATs_SuperGlue.py:217 and the numerator of both softmaxes of :218; for |score| <= 80 the max-subtraction of
+//     softmax is not needed for range).  E is written into the conf buffer; the tile's row sums (over its 64 columns)
+//     and column sums (over its 128 rows) go to partial buffers that conf_finalize_kernel reduces in a fixed order.
+//     RAW (1 / scale_factor > 80): the scaled scores themselves are written, no sums (max-subtracting path).
+//     A = point-major query descriptors MDT (row-major [n][256]), B = channel-major 3D descriptors MD.
 // =====================================================================================================
-using ScoreTile = GemmTile<SC_BM, SC_BN, 2, 2, true>;
-using ScoreTileW8 = GemmTile<SC_BM, SC_BN, 4, 2, true>;    // same tile on 8 waves
+using ScoreTileW8 = GemmTile<SC_BM, SC_BN, 4, 2, false>;    // 128x64 on 8 waves
 
-template <class T>
-__global__ __launch_bounds__(T::THREADS) void score_exp_kernel(const float* __restrict__ MD, float* __restrict__ conf,
-                                                               float* __restrict__ rowpart, float* __restrict__ colpart,
-                                                               ColLayout L, float scale) {
+template <class T, bool RAW>
+__global__ __launch_bounds__(T::THREADS) void score_exp_kernel(const float* __restrict__ MDT, const float* __restrict__ MD,
+                                                               float* __restrict__ conf, float* __restrict__ rowpart,
+                                                               float* __restrict__ colpart, ColLayout L, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nrt = L.n1p / T::BM, nct = L.n2p / T::BN;
     int rt, ct;
     const int frame = blockIdx.y;
     if (!xcd_tile_map(nrt, nct, rt, ct)) return;
     const int ld = L.ld;
-    const float* Ap = MD + (size_t)frame * L.np + rt * T::BM;            // [K][M] with row stride ld
+    const float* Ap = MDT + ((size_t)frame * L.n1p + rt * T::BM) * D;     // [M][K], row stride 256
     const float* Bp = MD + (size_t)frame * L.np + L.n1p + ct * T::BN;
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     gemm_mainloop<T>(
-        acc, smem, D / BK, [&](int kt) { return Ap + (size_t)kt * BK * ld; }, ld,
+        acc, smem, D / BK, [&](int kt) { return Ap + kt * BK; }, D,
         [&](int kt) { return Bp + (size_t)kt * BK * ld; }, ld);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
@@ -512,12 +507,13 @@ __global__ __launch_bounds__(T::THREADS) void score_exp_kernel(const float* __re
             const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);
             const int col = wn * 32 + l31;
             const int gi = rt * T::BM + row, gj = ct * T::BN + col;
-            Tl[row * TS + col] = (gi < L.n1 && gj < L.n2) ? expf(acc[tm][0][r] / scale) : 0.f;
+            const float sc = acc[tm][0][r] / scale;
+            Tl[row * TS + col] = (gi < L.n1 && gj < L.n2) ? (RAW ? sc : expf(sc)) : 0.f;
         }
     __syncthreads();
-    // E leaves through the LDS tile: 16 lanes cover one 256-byte row segment (16-byte stores when the rows of conf are
-    // 16-byte aligned, i.e. n2 % 4 == 0; otherwise 4-byte stores, 64 lanes per row segment)
-    if ((L.n2 & 3) == 0) {
+    // the tile leaves through LDS: 16 lanes cover one 256-byte row segment (16-byte stores when the rows of conf are
+    // 16-byte aligned, i.e. n2 % 4 == 0 and an aligned base; otherwise 4-byte stores, 64 lanes per row segment)
+    if ((L.n2 & 3) == 0 && (reinterpret_cast<uintptr_t>(cf) & 15) == 0) {
         for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
             const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
             const int gi = rt * T::BM + row, gj = ct * T::BN + c4;
@@ -534,7 +530,8 @@ __global__ __launch_bounds__(T::THREADS) void score_exp_kernel(const float* __re
             if (gi < L.n1 && gj < L.n2) cf[(size_t)gi * L.n2 + gj] = Tl[row * TS + col];
         }
     }
-    {   // row sums: THREADS / BM lanes per row; column sums: one wave per THREADS / 64-th of the rows (conflict-free
+    if constexpr (!RAW) {
+        // row sums: THREADS / BM lanes per row; column sums: one wave per THREADS / 64-th of the rows (conflict-free
         // column walks); fixed order throughout
         constexpr int LPR = T::THREADS / T::BM, CPL = T::BN / LPR;
         const int row = tid / LPR, hp = tid % LPR;
@@ -595,168 +592,147 @@ __global__ __launch_bounds__(256) void gats_wlt_kernel(const float* __restrict__
     }
 }
 
+// one-time split of the three big operators of every attention layer into bf16 hi / lo planes (AttnWB layout)
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ packed, unsigned short* __restrict__ packedb) {
+    const int layer = blockIdx.y;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const float* src = packed + PW_ATTN + (size_t)layer * AttnW::SIZE;
+    unsigned short* dst = packedb + (size_t)layer * AttnWB::SIZE;
+    constexpr size_t NQ = 768 * 256, N0 = 512 * 512, N3 = 256 * 512;
+    float x;
+    size_t hi, lo;
+    if (e < NQ) { x = src[AttnW::WQKV + e]; hi = AttnWB::QKV_HI + e; lo = AttnWB::QKV_LO + e; }
+    else if (e < NQ + N0) { x = src[AttnW::W0 + (e - NQ)]; hi = AttnWB::W0_HI + (e - NQ); lo = AttnWB::W0_LO + (e - NQ); }
+    else if (e < NQ + N0 + N3) { x = src[AttnW::W3 + (e - NQ - N0)]; hi = AttnWB::W3_HI + (e - NQ - N0); lo = AttnWB::W3_LO + (e - NQ - N0); }
+    else return;
+    const unsigned h = bf16_rne_bits(x);
+    dst[hi] = (unsigned short)h;
+    dst[lo] = (unsigned short)bf16_rne_bits(x - __uint_as_float(h << 16));
+}
+
+void launch_split_weights(const float* packed, unsigned short* packedb, hipStream_t s) {
+    constexpr size_t N = 768 * 256 + 512 * 512 + 256 * 512;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((N + 255) / 256), 8), dim3(256), 0, s, packed, packedb);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------------
-template <class T>
-constexpr size_t smem_bytes() { return sizeof(float) * T::SMEM_FLOATS; }
-
-// Residency shaping: the hardware workgroup dispatcher packs as many workgroups onto a CU as its
-// resources admit, so a grid of ~2 workgroups per CU whose kernel could fit 4 ends up with some CUs
-// holding 4 (taking 2x as long) and others idle.  Requesting 160 KiB / ceil(grid / 256) of LDS per
-// workgroup caps the residency at the balanced value.  Measured: no gain at one frame in flight, and it
-// blocks co-residency with other frames' kernels, so it is OFF unless GATSSPG_LDS_SHAPING=1.
-static size_t shaped_lds(size_t needed, int nblocks) {
-    static const bool on = [] { const char* v = getenv("GATSSPG_LDS_SHAPING"); return v && atoi(v) != 0; }();
-    if (!on) return needed;
-    const int per_cu = (nblocks + 255) / 256;
-    size_t bytes = ((size_t)160 * 1024 / (per_cu < 1 ? 1 : per_cu) - 2048) & ~(size_t)1023;
-    return bytes > needed ? bytes : needed;
+template <class T, int PREC = 0>
+constexpr size_t smem_bytes() {
+    size_t b = sizeof(float) * T::SMEM_FLOATS;
+    if constexpr (PREC == 1) {
+        if (Bf3Layout<T>::SMEM_BYTES > b) b = Bf3Layout<T>::SMEM_BYTES;
+    }
+    return b;
 }
 
-// kernels whose dynamic LDS request exceeds the 64 KiB default need the limit raised, once per device
-template <class K>
-void allow_big_lds(K kernel) {
+// Kernels whose dynamic LDS request exceeds the 64 KiB default need the limit raised once per device.  The once-flag
+// lives in a function template instantiated per KERNEL (the kernel is a non-type template argument), so two variants
+// that merely share a signature never share it.
+template <auto Kernel>
+void allow_big_lds() {
     static bool done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024 - 2048);
         if (dev >= 0 && dev < 64) done[dev] = true;
     }
 }
-#define GATSSPG_BIG_LDS_ONCE(kernel) allow_big_lds(kernel)
 
-// tuning knobs (read once): GATSSPG_MLP0_TILE / GATSSPG_MLP3_TILE select tile shapes, GATSSPG_VSTORE=0 switches the GEMM
-// epilogues back to 4-byte stores straight from the accumulators (default: 16-byte stores through an LDS tile)
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-// opt-in split-bf16 ("bf16x3") main loop (gemm_f32_mfma.h): GATSSPG_PREC=bf16x3 switches mlp0 (42.9 -> 34.9 us),
-// qkv_kv (38.0 -> 34.2 us) and mlp3 (27.9 -> 22.5 us on the 128x64 / 8-wave tile; its default 64x64 tile does not gain):
-// 1134 -> 1394 frames/s.  Per kernel: GATSSPG_MLP0_PREC / GATSSPG_QKV_PREC / GATSSPG_MLP3_PREC.
-// The default is the exact fp32 MFMA path.
-static bool split_bf16_enabled(const char* kernel_env, bool in_group = true) {
-    const char* a = getenv("GATSSPG_PREC");
-    const char* b = getenv(kernel_env);
-    return (in_group && a && !strcmp(a, "bf16x3")) || (b && !strcmp(b, "bf16x3"));
-}
-static int vec_store_enabled() {
-    static const int v = env_int("GATSSPG_VSTORE", 1);
-    return v;
-}
-
-template <class T, int PREC = 0>
-static void launch_qkv_t(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+template <class T, int PREC>
+static void launch_qkv_t(const float* Wqkv, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s,
+                         ProfileHook* hk) {
     const int NT = active_tiles(w.L);
-    auto kern = qkv_kv_kernel<T, PREC>;
-    GATSSPG_BIG_LDS_ONCE(kern);
-    size_t lds = smem_bytes<T>();
-    if (PREC == 1 && Bf3Layout<T>::SMEM_BYTES > lds) lds = Bf3Layout<T>::SMEM_BYTES;
-    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, kern, dim3(xcd_grid(6, NT)), dim3(T::THREADS), shaped_lds(lds, 6 * NT), s,
-                   Wqkv, bqkv, w.Z, w.Q, w.kvpart, w.L, vec_store_enabled());
+    allow_big_lds<qkv_kv_kernel<T, PREC>>();
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_kernel<T, PREC>), dim3(xcd_grid(6, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>()), s,
+                   Wqkv, bqkv, wb ? wb + AttnWB::QKV_HI : nullptr, wb ? wb + AttnWB::QKV_LO : nullptr, w.Z, w.Q, w.kvpart, w.L);
 }
 
-void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    static const int tq = env_int("GATSSPG_QKV_TILE", 1);   // 1 (default): the 128x64 tile on 8 waves (38.0 vs 40.1 us); 0: on 4
-    if (split_bf16_enabled("GATSSPG_QKV_PREC")) launch_qkv_t<QkvTileW8, 1>(Wqkv, bqkv, w, s, hk);
-    else if (tq == 1) launch_qkv_t<QkvTileW8>(Wqkv, bqkv, w, s, hk);
-    else launch_qkv_t<QkvTile>(Wqkv, bqkv, w, s, hk);
+void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s,
+                   ProfileHook* hk) {
+    if (w.prec == 1) launch_qkv_t<QkvTileB, 1>(Wqkv, bqkv, wb, w, s, hk);
+    else launch_qkv_t<QkvTileW8, 0>(Wqkv, bqkv, wb, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3(KVP / 64, w.nseg * H), dim3(1024), 0, s, w.kvpart,
                    w.kvfin, w.L);
 }
 
 void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook* hk) {
     const int NT = active_tiles(w.L);
-    GATSSPG_BIG_LDS_ONCE(attn_apply_kernel);
-    GATSSPG_LAUNCH(hk, KID_ATTN_APPLY, s, attn_apply_kernel, dim3(NT * H), dim3(256),
-                   shaped_lds(smem_bytes<ApplyTile>(), NT * H), s, w.kvfin, w.Q, w.MSG, w.L, cross);
+    allow_big_lds<attn_apply_kernel>();
+    GATSSPG_LAUNCH(hk, KID_ATTN_APPLY, s, attn_apply_kernel, dim3(NT * H), dim3(256), (smem_bytes<ApplyTile>()), s, w.kvfin,
+                   w.Q, w.MSG, w.L, cross);
 }
 
-
-template <class T, int ABL = 0, int PREC = 0>
-static void launch_mlp0_t(const float* W0, const float* b0, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    auto kern = mlp0_kernel<T, ABL, PREC>;
-    GATSSPG_BIG_LDS_ONCE(kern);
-    const int vec_store = vec_store_enabled();
+template <class T, int ABL, int PREC>
+static void launch_mlp0_t(const float* W0, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s,
+                          ProfileHook* hk) {
+    allow_big_lds<mlp0_kernel<T, ABL, PREC>>();
     const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
-    size_t lds = smem_bytes<T>();
-    if (PREC == 1 && Bf3Layout<T>::SMEM_BYTES > lds) lds = Bf3Layout<T>::SMEM_BYTES;
-    GATSSPG_LAUNCH(hk, KID_MLP0, s, kern, dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
-                   shaped_lds(lds, 512 / T::BM * NT), s, W0, b0, w.Z, w.MSG, w.U, w.statpart, w.L, g_trace, vec_store);
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_kernel<T, ABL, PREC>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
+                   (smem_bytes<T, PREC>()), s, W0, b0, wb ? wb + AttnWB::W0_HI : nullptr, wb ? wb + AttnWB::W0_LO : nullptr, w.Z,
+                   w.MSG, w.U, w.statpart, w.L, g_trace);
 }
-template <class T, int ABL = 0, int PREC = 0>
-static void launch_mlp3_t(const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    auto kern = mlp3_kernel<T, ABL, PREC>;
-    GATSSPG_BIG_LDS_ONCE(kern);
+template <class T, int ABL, int PREC>
+static void launch_mlp3_t(const float* W3, const float* b3, const unsigned short* wb, const Workspace& w, hipStream_t s,
+                          ProfileHook* hk) {
+    allow_big_lds<mlp3_kernel<T, ABL, PREC>>();
     const int NT = active_tiles(w.L) / (T::BN / 64);
-    size_t lds = smem_bytes<T>();
-    if (PREC == 1 && Bf3Layout<T>::SMEM_BYTES > lds) lds = Bf3Layout<T>::SMEM_BYTES;
-    GATSSPG_LAUNCH(hk, KID_MLP3, s, kern, dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), shaped_lds(lds, 256 / T::BM * NT), s,
-                   W3, b3, w.U, w.stats, w.Z, w.L, vec_store_enabled());
+    GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_kernel<T, ABL, PREC>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS),
+                   (smem_bytes<T, PREC>()), s, W3, b3, wb ? wb + AttnWB::W3_HI : nullptr, wb ? wb + AttnWB::W3_LO : nullptr, w.U,
+                   w.stats, w.Z, w.L);
 }
 
-void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const Workspace& w, hipStream_t s,
-                ProfileHook* hk) {
-    // GATSSPG_MLP0_TILE / GATSSPG_MLP3_TILE select alternative (equally correct) tile shapes; the
-    // ablation variants (wrong results, timing only) exist only in a -DGATSSPG_PROFILING_BUILD library.
-    // mlp0 default: 128x64 on 8 waves (one 32x32 MFMA tile per wave; measured 43.1 us vs 45.0 us for the 4-wave
-    // form of the same tile, 45.6 us for 128x128 on 8 waves).
-    static const int t0 = env_int("GATSSPG_MLP0_TILE", 2), t3 = env_int("GATSSPG_MLP3_TILE", 0);
+void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const unsigned short* wb, const Workspace& w,
+                hipStream_t s, ProfileHook* hk) {
+    // MLP0_TILE / MLP3_TILE / MLP0_BTILE select the alternative (equally correct) tile shapes in tuning builds; the ablation
+    // variants (wrong results, timing only) exist only in a -DGATSSPG_PROFILING_BUILD library.
+    static const int t0 = tuning_knob("MLP0_TILE", 0), t3 = tuning_knob("MLP3_TILE", 0), tb0 = tuning_knob("MLP0_BTILE", 0);
+    (void)t0;
+    if (w.prec == 1) {
+        if (tb0 == 1) launch_mlp0_t<Mlp0TileB8, 0, 1>(W0, b0, wb, w, s, hk);
+        else launch_mlp0_t<Mlp0TileB, 0, 1>(W0, b0, wb, w, s, hk);
+    }
 #ifdef GATSSPG_PROFILING_BUILD
-    if (t0 == 11) launch_mlp0_t<Mlp0Tile, 1>(W0, b0, w, s, hk);        // no global loads in the loop
-    else if (t0 == 12) launch_mlp0_t<Mlp0Tile, 2>(W0, b0, w, s, hk);   // no loads, no LDS writes
-    else if (t0 == 15) launch_mlp0_t<Mlp0Tile, 5>(W0, b0, w, s, hk);   // all workgroups stream the same (cache-hot) panels
-    else if (t0 == 16) launch_mlp0_t<Mlp0Tile, 6>(W0, b0, w, s, hk);   // every load L1-hot
-    else
+    else if (t0 == 11) launch_mlp0_t<Mlp0TileW8, 1, 0>(W0, b0, wb, w, s, hk);   // no global loads in the loop
+    else if (t0 == 12) launch_mlp0_t<Mlp0TileW8, 2, 0>(W0, b0, wb, w, s, hk);   // no loads, no LDS writes
+    else if (t0 == 15) launch_mlp0_t<Mlp0TileW8, 5, 0>(W0, b0, wb, w, s, hk);   // all workgroups stream the same (cache-hot) panels
+    else if (t0 == 16) launch_mlp0_t<Mlp0TileW8, 6, 0>(W0, b0, wb, w, s, hk);   // every load L1-hot
 #endif
-    static const bool bf3 = split_bf16_enabled("GATSSPG_MLP0_PREC"), bf3m3 = split_bf16_enabled("GATSSPG_MLP3_PREC");
-    if (bf3) launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, w, s, hk);
-    else if (t0 == 1) launch_mlp0_t<Mlp0TileWide>(W0, b0, w, s, hk);
-    else if (t0 == 2) launch_mlp0_t<Mlp0TileW8>(W0, b0, w, s, hk);
-    else if (t0 == 3) launch_mlp0_t<Mlp0TileBig>(W0, b0, w, s, hk);
-    else if (t0 == 4) launch_mlp0_t<Mlp0TileFlat>(W0, b0, w, s, hk);
-    else launch_mlp0_t<Mlp0Tile>(W0, b0, w, s, hk);
+    else launch_mlp0_t<Mlp0TileW8, 0, 0>(W0, b0, wb, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
+    if (w.prec == 1) launch_mlp3_t<Mlp3TileB, 0, 1>(W3, b3, wb, w, s, hk);
 #ifdef GATSSPG_PROFILING_BUILD
-    if (t3 == 11) launch_mlp3_t<Mlp3Tile, 1>(W3, b3, w, s, hk);
-    else if (t3 == 12) launch_mlp3_t<Mlp3Tile, 2>(W3, b3, w, s, hk);
-    else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3>(W3, b3, w, s, hk);   // steady-state loop cut: fixed cost only
-    else
+    else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3, 0>(W3, b3, wb, w, s, hk);   // steady-state loop cut: fixed cost only
 #endif
-    if (bf3m3) launch_mlp3_t<Mlp3TileTallW8, 0, 1>(W3, b3, w, s, hk);   // 128x64 on 8 waves: the 64x64 tile does not gain from the split loop
-    else if (t3 == 1) launch_mlp3_t<Mlp3TileTall>(W3, b3, w, s, hk);
-    else if (t3 == 2) launch_mlp3_t<Mlp3TileWide>(W3, b3, w, s, hk);
-    else if (t3 == 3) launch_mlp3_t<Mlp3TileTallW8>(W3, b3, w, s, hk);
-    else if (t3 == 4) launch_mlp3_t<Mlp3TileWideW8>(W3, b3, w, s, hk);
-    else launch_mlp3_t<Mlp3Tile>(W3, b3, w, s, hk);
+    else if (t3 == 1) launch_mlp3_t<Mlp3TileTallW8, 0, 0>(W3, b3, wb, w, s, hk);
+    else launch_mlp3_t<Mlp3Tile, 0, 0>(W3, b3, wb, w, s, hk);
 }
 
 void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    GATSSPG_BIG_LDS_ONCE(final_proj_norm_kernel);
+    allow_big_lds<final_proj_norm_kernel>();
     GATSSPG_LAUNCH(hk, KID_FINAL_PROJ, s, final_proj_norm_kernel, dim3(w.L.ld / FinalTile::BN), dim3(256),
-                   smem_bytes<FinalTile>(), s, Wf, bf, w.Z, w.MD, w.L);
+                   (smem_bytes<FinalTile>()), s, Wf, bf, w.Z, w.MD, w.MDT, w.L);
 }
 
-template <class T>
+template <bool RAW>
 static void launch_score_t(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk) {
-    auto kern = score_exp_kernel<T>;
-    GATSSPG_BIG_LDS_ONCE(kern);
-    GATSSPG_LAUNCH(hk, KID_SCORE_EXP, s, kern, dim3(xcd_grid(w.sc_nrt, w.sc_nct), w.L.b), dim3(T::THREADS),
-                   shaped_lds(smem_bytes<T>(), w.sc_nrt * w.sc_nct * w.L.b), s, w.MD, conf, w.rowpart, w.colpart, w.L, scale);
+    using T = ScoreTileW8;
+    allow_big_lds<score_exp_kernel<T, RAW>>();
+    GATSSPG_LAUNCH(hk, KID_SCORE_EXP, s, (score_exp_kernel<T, RAW>), dim3(xcd_grid(w.sc_nrt, w.sc_nct), w.L.b), dim3(T::THREADS),
+                   (smem_bytes<T>()), s, w.MDT, w.MD, conf, w.rowpart, w.colpart, w.L, scale);
 }
 
-void launch_score_exp(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk) {
-    static const int ts = env_int("GATSSPG_SCORE_TILE", 1);   // 1 (default): the 128x64 tile on 8 waves (45.2 vs 52.3 us); 0: on 4
-    if (ts == 1) launch_score_t<ScoreTileW8>(w, conf, scale, s, hk);
-    else launch_score_t<ScoreTile>(w, conf, scale, s, hk);
+void launch_score_exp(const Workspace& w, float* conf, float scale, int shifted, hipStream_t s, ProfileHook* hk) {
+    if (shifted) launch_score_t<true>(w, conf, scale, s, hk);
+    else launch_score_t<false>(w, conf, scale, s, hk);
 }
 
 void launch_gats_wlt(const float* W, const float* P, const Workspace& w, int add_h, hipStream_t s, ProfileHook* hk) {
     const int NT = w.L.ld / WltTile::BN;
-    GATSSPG_LAUNCH(hk, KID_GATS_WLT, s, gats_wlt_kernel, dim3(xcd_grid(4, NT)), dim3(256), smem_bytes<WltTile>(), s, W, P, w.Z,
+    GATSSPG_LAUNCH(hk, KID_GATS_WLT, s, gats_wlt_kernel, dim3(xcd_grid(4, NT)), dim3(256), (smem_bytes<WltTile>()), s, W, P, w.Z,
                    w.L, add_h);
 }
 

@@ -7,8 +7,8 @@ namespace gatsspg {
 // Kernel ids (also the `kernel_id` of gatsspg_forward_profiled, include/gatsspg.h)
 enum KernelId {
     KID_LOAD_STATE = 0, KID_GATS = 1, KID_QKV_KV = 2, KID_KV_FINAL = 3, KID_ATTN_APPLY = 4, KID_MLP0 = 5,
-    KID_STAT_FINAL = 6, KID_MLP3 = 7, KID_FINAL_PROJ = 8, KID_SCORE_EXP = 9, KID_SOFTMAX_SUMS = 10,
-    KID_CONF_FINALIZE = 11, KID_MATCH_REDUCE = 12, KID_MATCH_TAIL = 13, KID_GATS_WLT = 14, KID_COUNT = 15
+    KID_STAT_FINAL = 6, KID_MLP3 = 7, KID_FINAL_PROJ = 8, KID_SCORE_EXP = 9, KID_CONF_FINALIZE = 10,
+    KID_MATCH_TAIL = 11, KID_GATS_WLT = 12, KID_SOFTMAX_STATS = 13, KID_COUNT = 14
 };
 
 // Optional HIP-event bracket around the `occurrence`-th launch of kernel `kernel_id` inside one forward
@@ -33,26 +33,41 @@ inline void hook_after(ProfileHook* h, int kid, hipStream_t s) {
         hook_after(hook, kid, stream);              \
     } while (0)
 
+// Tuning knobs.  The product library has NO environment lookups: every knob is its compiled-in default.  A library built
+// with -DGATSSPG_TUNING (python -m onepose_amd.build_ext --tuning -> libgatsspg_hip_tuning.so, never loaded by the
+// package) reads GATSSPG_<NAME> from the environment once, for A/B runs of alternative tile shapes (tools/ab_tuning.py).
+int tuning_knob(const char* name, int dflt);
+
 // gatsspg_gemm_kernels.hip
 #ifdef GATSSPG_PROFILING_BUILD
 extern unsigned long long* g_trace;  // per-workgroup timeline buffer of mlp0_kernel (nullptr = off)
 #endif
-void launch_qkv_kv(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+// packedb: the split-bf16 weight planes of this layer (AttnWB offsets), used when w.prec == 1
+void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* packedb, const Workspace& w, hipStream_t s,
+                   ProfileHook* hk = nullptr);
 void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook* hk = nullptr);
-void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const unsigned short* packedb,
+                const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
-void launch_score_exp(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk = nullptr);
+// shifted = 0: E = exp(S) into conf + row/col sum partials (|S| <= 80); 1: raw scores S into conf (max-subtracting path)
+void launch_score_exp(const Workspace& w, float* conf, float scale, int shifted, hipStream_t s, ProfileHook* hk = nullptr);
 void launch_gats_wlt(const float* W, const float* P, const Workspace& w, int add_h, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_split_weights(const float* packed, unsigned short* packedb, hipStream_t s);
 
 // gatsspg_stream_kernels.hip
 void launch_load_state(const float* dq, const float* d3, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 // copies compact [b,256,n] columns of one or both sides into `dst` ([256][ld]); a null side is left untouched
 void launch_load_columns(const float* c2, const float* c3, float* dst, const Workspace& w, hipStream_t s);
 void launch_store_state(const float* src, float* out2d, float* out3d, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+// h3: where the layer reads the 3D-point descriptors from: nullptr = the state Z; otherwise the caller's compact
+// [b,256,n2] tensor (first layer of a forward: the state load is fused, `dq` is copied into the 2D side by spare workgroups)
 void launch_gats(const float* u1, const float* u2, const float* leaves, int num_leaf, int flags, float* dst,
-                 const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
-void launch_dual_softmax_match(const Workspace& w, float* conf, float match_threshold, int64_t* matches0,
-                               int64_t* matches1, float* mscores0, float* mscores1, hipStream_t s,
+                 const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr, const float* h3 = nullptr,
+                 const float* dq = nullptr);
+// true if launch_gats can take h3 / dq for this configuration (fused state load)
+bool gats_fuses_state_load(int num_leaf, int flags, const Workspace& w);
+void launch_dual_softmax_match(const Workspace& w, float* conf, float scale, int shifted, float match_threshold,
+                               int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, hipStream_t s,
                                ProfileHook* hk = nullptr);
 void launch_pack_weights(const void* raw_struct_host, float* packed, hipStream_t s);
 size_t kenc_scratch_bytes(int b, int n);

@@ -2,12 +2,25 @@
 // aggregation, the dual-softmax finalisation with row/column arg-max, the mutual-NN tail, the
 // one-time weight packing and the (off-path) KeypointEncoder.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "../../include/gatsspg.h"
 #include "gatsspg_launch.h"
 
 namespace gatsspg {
+
+int tuning_knob(const char* name, int dflt) {
+#ifdef GATSSPG_TUNING
+    char key[96];
+    snprintf(key, sizeof(key), "GATSSPG_%s", name);
+    const char* v = getenv(key);
+    return v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expm1f(x); }
 
@@ -81,126 +94,46 @@ void launch_store_state(const float* src, float* out2d, float* out3d, const Work
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : 0.2f * x; }
 
-// fast path, num_leaf == 8: 8 points (64 leaf columns) x 256 channels per workgroup, the whole
-// [256 x 64] leaf tile lives in registers (16 float4 per thread), every HBM byte is read once.
-__global__ __launch_bounds__(256) void gats_leaf8_kernel(const float* __restrict__ u1, const float* __restrict__ u2,
-                                                         const float* __restrict__ leaves, const float* Z,
-                                                         float* dst, ColLayout L, int flags, int raw_out) {
-    // Z and dst alias when the layer updates the state in place (no __restrict__ on them)
-    __shared__ float hs[D * 8];
-    __shared__ float red3[4][8];
-    __shared__ float redl[4][64];
-    __shared__ float coef[8][9];
-    const int f = blockIdx.y, n0 = blockIdx.x * 8;
-    const int pv = min(8, L.n2 - n0);
-    const size_t lrow = (size_t)L.n2 * 8;
-    const float* Lf = leaves + (size_t)f * D * lrow + (size_t)n0 * 8;
-    const size_t ycol = (size_t)f * L.np + L.n1p + n0;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane >> 4, c4 = lane & 15;
-    const int pt = c4 >> 1, lh = c4 & 1;
-    const bool valid = pt < pv;
-
-    float4 v[16];
-    float u1r[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const int ch = p * 16 + w * 4 + r;
-        v[p] = valid ? *reinterpret_cast<const float4*>(Lf + (size_t)ch * lrow + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        u1r[p] = u1[ch];
-    }
-    // 3D-point descriptors h[ch][8 points] (state columns are padded, always in bounds)
-    float hv[8];
-    {
-        const float4* zp = reinterpret_cast<const float4*>(Z + (size_t)tid * L.ld + ycol);
-        const float4 a = zp[0], b = zp[1];
-        hv[0] = a.x; hv[1] = a.y; hv[2] = a.z; hv[3] = a.w; hv[4] = b.x; hv[5] = b.y; hv[6] = b.z; hv[7] = b.w;
-        const float u2v = u2[tid];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            hs[tid * 8 + i] = hv[i];
-            float s = hv[i] * u2v;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) red3[w][i] = s;
-        }
-    }
-    {
-        float dl[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            dl[0] += v[p].x * u1r[p]; dl[1] += v[p].y * u1r[p]; dl[2] += v[p].z * u1r[p]; dl[3] += v[p].w * u1r[p];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            dl[j] += __shfl_xor(dl[j], 16);
-            dl[j] += __shfl_xor(dl[j], 32);
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) redl[w][c4 * 4 + j] = dl[j];
-        }
-    }
-    __syncthreads();
-    if (tid < 8) {
-        const int include_self = flags & GATSSPG_FLAG_INCLUDE_SELF;
-        const float s3 = (red3[0][tid] + red3[1][tid]) + (red3[2][tid] + red3[3][tid]);
-        float e[9];
-        e[0] = lrelu02(s3 + s3);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = tid * 8 + j;
-            e[1 + j] = lrelu02(s3 + ((redl[0][c] + redl[1][c]) + (redl[2][c] + redl[3][c])));
-        }
-        float m = include_self ? e[0] : e[1];
-#pragma unroll
-        for (int j = 1; j < 9; ++j) m = fmaxf(m, e[j]);
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            if (j > 0 || include_self) {
-                e[j] = expf(e[j] - m);
-                sum += e[j];
-            }
-        }
-        if (include_self) {
-            coef[tid][0] = e[0] / sum + ((flags & GATSSPG_FLAG_ADDITIONAL) && !raw_out ? 1.f : 0.f);
-#pragma unroll
-            for (int j = 1; j < 9; ++j) coef[tid][j] = e[j] / sum;
-        } else {
-            coef[tid][0] = 1.f;
-#pragma unroll
-            for (int j = 1; j < 9; ++j) coef[tid][j] = (e[j] / sum) / 2.f;
-        }
-    }
-    __syncthreads();
-    const float c0 = coef[pt][0];
-    const float cj0 = coef[pt][1 + lh * 4 + 0], cj1 = coef[pt][1 + lh * 4 + 1];
-    const float cj2 = coef[pt][1 + lh * 4 + 2], cj3 = coef[pt][1 + lh * 4 + 3];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const int ch = p * 16 + w * 4 + r;
-        float part = ((cj0 * v[p].x + cj1 * v[p].y) + (cj2 * v[p].z + cj3 * v[p].w));
-        part += __shfl_xor(part, 1);
-        if (lh == 0 && valid) {
-            const float val = c0 * hs[ch * 8 + pt] + part;
-            dst[(size_t)ch * L.ld + ycol + pt] = raw_out ? val : elu_f(val);
-        }
-    }
-}
-
 // num_leaf == 8, 4 points (32 leaf columns = one 128-byte line per channel row) per workgroup: 8 float4 per
 // thread (~70 VGPRs -> 7 workgroups per CU, 224 KiB of loads in flight per CU) and 2x more workgroups
 // than the 8-point variant (finer tail).  Consecutive tiles are mapped to the same XCD (workgroup id g
 // runs on XCD g % 8) so the 16-byte output pieces of one 128-byte line meet in one L2.
+// Fused state load (first layer of a forward): h3 != nullptr -> the 3D-point descriptors are read straight from the
+// caller's compact [b,256,n2] tensor instead of the state, and GATS_COPY_BLOCKS spare workgroups per frame copy the
+// query descriptors dq [b,256,n1] into the 2D side of the state (pads zeroed) and zero the 3D-side pad columns --
+// what load_state_kernel would have done in a launch of its own.
+constexpr int GATS_COPY_BLOCKS = 64;   // 4 channel rows each
+
+template <bool FUSED_LOAD>
 __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __restrict__ u1, const float* __restrict__ u2,
                                                            const float* __restrict__ leaves, const float* Z, float* dst,
-                                                           ColLayout L, int flags, int raw_out, int ntiles) {
+                                                           ColLayout L, int flags, int raw_out, int ntiles,
+                                                           const float* __restrict__ h3, const float* __restrict__ dq) {
     __shared__ float hs[D * 4];
     __shared__ float red3[4][4];
     __shared__ float redl[4][32];
     __shared__ float coef[4][9];
     const int f = blockIdx.y;
+    if (FUSED_LOAD && (int)blockIdx.x >= ntiles) {   // state-load role
+        const int ch = ((int)blockIdx.x - ntiles) * 4 + (threadIdx.x >> 6), ln = threadIdx.x & 63;
+        float* zr = dst + (size_t)ch * L.ld + (size_t)f * L.np;
+        const float* q = dq + ((size_t)f * D + ch) * L.n1;
+        const bool vec = (L.n1 & 3) == 0;
+        for (int i = ln * 4; i < L.n1p; i += 256) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (vec && i + 3 < L.n1) {
+                v = *reinterpret_cast<const float4*>(q + i);
+            } else {
+                if (i < L.n1) v.x = q[i];
+                if (i + 1 < L.n1) v.y = q[i + 1];
+                if (i + 2 < L.n1) v.z = q[i + 2];
+                if (i + 3 < L.n1) v.w = q[i + 3];
+            }
+            *reinterpret_cast<float4*>(zr + i) = v;
+        }
+        for (int i = L.n2 + ln; i < L.n2p; i += 64) zr[L.n1p + i] = 0.f;
+        return;
+    }
     // bijective XCD-contiguous remap (cdna guide T1, non-multiple-of-8 safe)
     int tile;
     {
@@ -226,7 +159,20 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
         u1r[p] = u1[ch];
     }
     {
-        const float4 a = *reinterpret_cast<const float4*>(Z + (size_t)tid * L.ld + ycol);
+        float4 a;
+        if (FUSED_LOAD) {
+            const float* hp = h3 + ((size_t)f * D + tid) * L.n2 + n0;
+            if (pv == 4 && (L.n2 & 3) == 0) {
+                a = *reinterpret_cast<const float4*>(hp);
+            } else {
+                a.x = hp[0];
+                a.y = pv > 1 ? hp[1] : 0.f;
+                a.z = pv > 2 ? hp[2] : 0.f;
+                a.w = pv > 3 ? hp[3] : 0.f;
+            }
+        } else {
+            a = *reinterpret_cast<const float4*>(Z + (size_t)tid * L.ld + ycol);
+        }
         const float hv[4] = {a.x, a.y, a.z, a.w};
         const float u2v = u2[tid];
 #pragma unroll
@@ -384,17 +330,22 @@ __global__ __launch_bounds__(256) void gats_generic_kernel(const float* __restri
     }
 }
 
+bool gats_fuses_state_load(int num_leaf, int flags, const Workspace& w) {
+    return num_leaf == 8 && !(flags & GATSSPG_FLAG_WITH_LINEAR_TRANSFORM) && w.L.tw_first == 0 && w.L.tw_count == w.L.np / 64;
+}
+
 void launch_gats(const float* u1, const float* u2, const float* leaves, int num_leaf, int flags, float* dst,
-                 const Workspace& w, hipStream_t s, ProfileHook* hk) {
+                 const Workspace& w, hipStream_t s, ProfileHook* hk, const float* h3, const float* dq) {
     const int raw_out = (flags & GATSSPG_FLAG_WITH_LINEAR_TRANSFORM) ? 1 : 0;
-    static const int variant = [] { const char* v = getenv("GATSSPG_GATS_TILE"); return v ? atoi(v) : 4; }();
-    if (num_leaf == 8 && variant == 4) {
+    if (num_leaf == 8) {
         const int nt = (w.L.n2 + 3) / 4;
-        GATSSPG_LAUNCH(hk, KID_GATS, s, gats_leaf8x4_kernel, dim3(nt, w.L.b), dim3(256), 0, s, u1, u2, leaves, w.Z, dst, w.L,
-                       flags, raw_out, nt);
-    } else if (num_leaf == 8) {
-        GATSSPG_LAUNCH(hk, KID_GATS, s, gats_leaf8_kernel, dim3((w.L.n2 + 7) / 8, w.L.b), dim3(256), 0, s, u1, u2, leaves, w.Z,
-                       dst, w.L, flags, raw_out);
+        const int extra = h3 ? GATS_COPY_BLOCKS : 0;
+        if (h3)
+            GATSSPG_LAUNCH(hk, KID_GATS, s, gats_leaf8x4_kernel<true>, dim3(nt + extra, w.L.b), dim3(256), 0, s, u1, u2, leaves, w.Z,
+                           dst, w.L, flags, raw_out, nt, h3, dq);
+        else
+            GATSSPG_LAUNCH(hk, KID_GATS, s, gats_leaf8x4_kernel<false>, dim3(nt, w.L.b), dim3(256), 0, s, u1, u2, leaves, w.Z, dst,
+                           w.L, flags, raw_out, nt, h3, dq);
     } else {
         GATSSPG_LAUNCH(hk, KID_GATS, s, gats_generic_kernel, dim3((w.L.n2 + 3) / 4, w.L.b), dim3(256), 0, s, u1, u2, leaves,
                        w.Z, dst, w.L, num_leaf, flags, raw_out);
@@ -404,34 +355,6 @@ void launch_gats(const float* u1, const float* u2, const float* leaves, int num_
 // ------------------------------------------------------------------------------------------------------
 // dual softmax finalisation + matching     (GATs_SuperGlue.py:218-237)
 // ------------------------------------------------------------------------------------------------------
-// row sums (over n2) and column sums (over n1) of E from the score kernel's per-tile partials.
-// 1024 threads = 64 outputs x 16 partial-ranges; ranges are summed in order and combined in order.
-__global__ __launch_bounds__(1024) void softmax_sums_kernel(const float* __restrict__ rowpart,
-                                                            const float* __restrict__ colpart, float* __restrict__ rs,
-                                                            float* __restrict__ cs, ColLayout L, int nct, int nrt) {
-    __shared__ float red[16][64];
-    const int f = blockIdx.y, el = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int nrb = L.n1p / 64;
-    const bool rows = (int)blockIdx.x < nrb;
-    const int idx = (rows ? blockIdx.x : blockIdx.x - nrb) * 64 + el;
-    const int T = rows ? nct : nrt;
-    const size_t stride = rows ? L.n1p : L.n2p;
-    const float* src = (rows ? rowpart : colpart) + (size_t)f * T * stride + idx;
-    const int per = (T + 15) / 16;
-    const int tb = part * per, te = min(T, tb + per);
-    float s = 0.f;
-#pragma unroll 8
-    for (int t = tb; t < te; ++t) s += src[(size_t)t * stride];
-    red[part][el] = s;
-    __syncthreads();
-    if (part == 0) {
-        float tot = red[0][el];
-#pragma unroll
-        for (int p = 1; p < 16; ++p) tot += red[p][el];
-        (rows ? rs : cs)[(size_t)f * stride + idx] = tot;
-    }
-}
-
 __device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
     if (ov > v || (ov == v && oi < i)) {
         v = ov;
@@ -439,75 +362,162 @@ __device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int o
     }
 }
 
-// conf = softmax(S, dim=1) * softmax(S, dim=2) = (E / colsum) * (E / rowsum), in place over E;
-// per 8-row strip the column (max, first arg-max row), per 1024-column chunk the row (max, first
-// arg-max column).  torch.max on CPU breaks ties with the first index; so do we.
-// VEC: n2 % 4 == 0 -> each thread owns 4 consecutive columns (16-byte accesses); otherwise columns
-// tid + 256 k.
-template <bool VEC>
-__global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ conf, const float* __restrict__ rs,
-                                                            const float* __restrict__ cs, float* __restrict__ rmax_v,
+// conf = softmax(S, dim=1) * softmax(S, dim=2)  (GATs_SuperGlue.py:218), in place over the conf buffer, for a strip of
+// CF_ROWS rows x a chunk of CF_COLS columns per workgroup; per strip the column (max, first arg-max row), per chunk the
+// row (max, first arg-max column).  torch.max on CPU breaks ties with the first index; so do we.
+//   SHIFTED = false: the buffer holds E = exp(S) (score_exp_kernel); conf = (E / colsum) * (E / rowsum).  The two
+//     normalisers are summed here, in the prologue, from the score kernel's per-tile partials (rows: this strip's
+//     CF_ROWS sums of nct partials; columns: this chunk's CF_COLS sums of nrt partials) -- no reduction launch.
+//   SHIFTED = true (1 / scale_factor > 80): the buffer holds S; conf = exp(S - colmax)/colsum * exp(S - rowmax)/rowsum
+//     with the maxima / sums precomputed by softmax_rowstat / softmax_colstat (the max-subtracting softmax, total range).
+// Each wave owns 4 whole rows of the strip (16 columns per lane and row, 16 x 16 B in flight per lane): the row arg-max
+// needs one butterfly per row and wave, the column arg-max is combined across the 4 waves through LDS.
+// VEC: n2 % 4 == 0 and conf 16-byte aligned -> a lane owns 4 x 4 consecutive columns; otherwise columns lane + 64 k.
+template <bool VEC, bool SHIFTED>
+__global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ conf, const float* __restrict__ rowpart,
+                                                            const float* __restrict__ colpart, const float* __restrict__ rs_g,
+                                                            const float* __restrict__ cs_g, const float* __restrict__ rshift,
+                                                            const float* __restrict__ cshift, float* __restrict__ rmax_v,
                                                             int* __restrict__ rmax_i, float* __restrict__ cmax_v,
-                                                            int* __restrict__ cmax_i, ColLayout L, int nch, int nst) {
-    __shared__ float wv[CF_ROWS][4];
-    __shared__ int wi[CF_ROWS][4];
+                                                            int* __restrict__ cmax_i, ColLayout L, int nct, int nrt, int nch,
+                                                            int nst) {
+    __shared__ __attribute__((aligned(16))) float cs_s[CF_COLS];
+    __shared__ __attribute__((aligned(16))) float csh_s[SHIFTED ? CF_COLS : 4];
+    __shared__ float red[16][CF_ROWS];
+    __shared__ float rs_s[CF_ROWS], rsh_s[CF_ROWS];
+    __shared__ __attribute__((aligned(16))) float cmv_s[4][CF_COLS];
+    __shared__ __attribute__((aligned(16))) int cmi_s[4][CF_COLS];
     const int chk = blockIdx.x, st = blockIdx.y, f = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = st * CF_ROWS, j0 = chk * CF_COLS;
-    float* cf = conf + (size_t)f * L.n1 * L.n2;
-    int jc[4];
-    float csj[4], cmv[4];
-    int cmi[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        jc[k] = VEC ? j0 + 4 * tid + k : j0 + tid + 256 * k;
-        csj[k] = jc[k] < L.n2 ? cs[(size_t)f * L.n2p + jc[k]] : 1.f;
-        cmv[k] = -INFINITY;
-        cmi[k] = 0;
-    }
     const int nrows = min(CF_ROWS, L.n1 - i0);
-    // all CF_ROWS rows of the strip are fetched before any is processed: CF_ROWS x 16 B in flight per thread
-    float e[CF_ROWS][4];
-#pragma unroll
-    for (int u = 0; u < CF_ROWS; ++u) {
-        const size_t base = (size_t)(i0 + u) * L.n2;
-        if (u < nrows) {
-            if (VEC) {
-                if (jc[0] < L.n2) {
-                    const float4 x = *reinterpret_cast<const float4*>(cf + base + jc[0]);
-                    e[u][0] = x.x; e[u][1] = x.y; e[u][2] = x.z; e[u][3] = x.w;
+    float* cf = conf + (size_t)f * L.n1 * L.n2;
+
+    // ---- normalisers of this strip's rows and this chunk's columns ----
+    if constexpr (!SHIFTED) {
+        {
+            const int r = tid & (CF_ROWS - 1), g = tid / CF_ROWS;   // 16 rows x 16 partial ranges
+            const int per = (nct + 15) / 16;
+            const int tb = g * per, te = min(nct, tb + per);
+            float s = 0.f;
+            if (r < nrows) {
+                const float* src = rowpart + (size_t)f * nct * L.n1p + i0 + r;
+#pragma unroll 4
+                for (int t = tb; t < te; ++t) s += src[(size_t)t * L.n1p];
+            }
+            red[g][r] = s;
+        }
+        {
+            const int jl = 4 * tid, j = j0 + jl;                    // 4 consecutive columns per thread
+            float4 c = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (j < L.n2p) {                                        // n2p is a multiple of 128: all four in bounds
+                const float* src = colpart + (size_t)f * nrt * L.n2p + j;
+                const int per = (nrt + 15) / 16;
+                for (int r = 0; r < 16; ++r) {
+                    const int tb = r * per, te = min(nrt, tb + per);
+                    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int t = tb; t < te; ++t) {
+                        const float4 x = *reinterpret_cast<const float4*>(src + (size_t)t * L.n2p);
+                        s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+                    }
+                    if (r == 0) c = s;
+                    else { c.x += s.x; c.y += s.y; c.z += s.z; c.w += s.w; }
                 }
-            } else {
+            }
+            *reinterpret_cast<float4*>(cs_s + jl) = c;
+        }
+        __syncthreads();
+        if (tid < CF_ROWS) {
+            float tot = red[0][tid];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (jc[k] < L.n2) e[u][k] = cf[base + jc[k]];
+            for (int p = 1; p < 16; ++p) tot += red[p][tid];
+            rs_s[tid] = tot;
+        }
+    } else {
+        for (int jl = tid; jl < CF_COLS; jl += 256) {
+            const int j = j0 + jl;
+            cs_s[jl] = j < L.n2 ? cs_g[(size_t)f * L.n2p + j] : 1.f;
+            csh_s[jl] = j < L.n2 ? cshift[(size_t)f * L.n2p + j] : 0.f;
+        }
+        if (tid < CF_ROWS) {
+            const bool ok = tid < nrows;
+            rs_s[tid] = ok ? rs_g[(size_t)f * L.n1p + i0 + tid] : 1.f;
+            rsh_s[tid] = ok ? rshift[(size_t)f * L.n1p + i0 + tid] : 0.f;
+        }
+    }
+
+    // ---- this wave's 4 rows: all 16 x 16 B of a lane are requested before any is used ----
+    auto lcol = [&](int q, int k) { return VEC ? 4 * lane + 256 * q + k : lane + 64 * (4 * q + k); };
+    float e[4][4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = 4 * wave + u;
+        if (r < nrows) {   // wave-uniform
+            const size_t base = (size_t)(i0 + r) * L.n2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (VEC) {
+                    const int j = j0 + lcol(q, 0);
+                    if (j < L.n2) {
+                        const float4 x = *reinterpret_cast<const float4*>(cf + base + j);
+                        e[u][q][0] = x.x; e[u][q][1] = x.y; e[u][q][2] = x.z; e[u][q][3] = x.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int j = j0 + lcol(q, k);
+                        if (j < L.n2) e[u][q][k] = cf[base + j];
+                    }
+                }
             }
         }
     }
+    __syncthreads();   // normalisers visible
+    float csj[4][4], cshj[4][4], cmv[4][4];
+    int cmi[4][4];
 #pragma unroll
-    for (int u = 0; u < CF_ROWS; ++u) {
-        const int r = u;
-        if (r < nrows) {  // uniform over the block
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            csj[q][k] = cs_s[lcol(q, k)];
+            cshj[q][k] = SHIFTED ? csh_s[lcol(q, k)] : 0.f;
+            cmv[q][k] = -INFINITY;
+            cmi[q][k] = 0;
+        }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = 4 * wave + u;
+        if (r < nrows) {
             const int i = i0 + r;
             const size_t base = (size_t)i * L.n2;
-            const float rsi = rs[(size_t)f * L.n1p + i];
+            const float rsi = rs_s[r];
+            const float rshi = SHIFTED ? rsh_s[r] : 0.f;
             float rv = -INFINITY;
             int ri = 0x7fffffff;
-            float c[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (jc[k] < L.n2) {
-                    c[k] = (e[u][k] / csj[k]) * (e[u][k] / rsi);
-                    if (c[k] > cmv[k]) { cmv[k] = c[k]; cmi[k] = i; }
-                    if (c[k] > rv) { rv = c[k]; ri = jc[k]; }
+            for (int q = 0; q < 4; ++q) {
+                float c[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = j0 + lcol(q, k);
+                    if (j < L.n2) {
+                        const float x = e[u][q][k];
+                        if constexpr (SHIFTED) c[k] = (expf(x - cshj[q][k]) / csj[q][k]) * (expf(x - rshi) / rsi);
+                        else c[k] = (x / csj[q][k]) * (x / rsi);
+                        if (c[k] > cmv[q][k]) { cmv[q][k] = c[k]; cmi[q][k] = i; }
+                        if (c[k] > rv || (c[k] == rv && j < ri)) { rv = c[k]; ri = j; }
+                    }
                 }
-            }
-            if (VEC) {
-                if (jc[0] < L.n2) *reinterpret_cast<float4*>(cf + base + jc[0]) = make_float4(c[0], c[1], c[2], c[3]);
-            } else {
+                if (VEC) {
+                    const int j = j0 + lcol(q, 0);
+                    if (j < L.n2) *reinterpret_cast<float4*>(cf + base + j) = make_float4(c[0], c[1], c[2], c[3]);
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (jc[k] < L.n2) cf[base + jc[k]] = c[k];
+                    for (int k = 0; k < 4; ++k) {
+                        const int j = j0 + lcol(q, k);
+                        if (j < L.n2) cf[base + j] = c[k];
+                    }
+                }
             }
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) {
@@ -515,122 +525,164 @@ __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ 
                 const int oi = __shfl_xor(ri, o);
                 argmax_combine(rv, ri, ov, oi);
             }
-            if (lane == 0) { wv[r][wave] = rv; wi[r][wave] = ri; }
+            if (lane == 0) {
+                rmax_v[((size_t)f * nch + chk) * L.n1p + i] = rv;
+                rmax_i[((size_t)f * nch + chk) * L.n1p + i] = ri;
+            }
         }
     }
-    __syncthreads();
-    if (tid < nrows) {
-        float v = wv[tid][0];
-        int i = wi[tid][0];
-        for (int q = 1; q < 4; ++q) argmax_combine(v, i, wv[tid][q], wi[tid][q]);
-        rmax_v[((size_t)f * nch + chk) * L.n1p + i0 + tid] = v;
-        rmax_i[((size_t)f * nch + chk) * L.n1p + i0 + tid] = i;
-    }
+    // ---- column maxima of the strip: the 4 waves (ascending rows) are combined in order, strict '>' keeps the first row ----
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (jc[k] < L.n2) {
-            cmax_v[((size_t)f * nst + st) * L.n2p + jc[k]] = cmv[k];
-            cmax_i[((size_t)f * nst + st) * L.n2p + jc[k]] = cmi[k];
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cmv_s[wave][lcol(q, k)] = cmv[q][k];
+            cmi_s[wave][lcol(q, k)] = cmi[q][k];
+        }
+    __syncthreads();
+    {
+        const int jl = 4 * tid, j = j0 + jl;
+        if (j < L.n2p) {
+            float4 v = *reinterpret_cast<const float4*>(&cmv_s[0][jl]);
+            int4 a = *reinterpret_cast<const int4*>(&cmi_s[0][jl]);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 ov = *reinterpret_cast<const float4*>(&cmv_s[w][jl]);
+                const int4 oa = *reinterpret_cast<const int4*>(&cmi_s[w][jl]);
+                if (ov.x > v.x) { v.x = ov.x; a.x = oa.x; }
+                if (ov.y > v.y) { v.y = ov.y; a.y = oa.y; }
+                if (ov.z > v.z) { v.z = ov.z; a.z = oa.z; }
+                if (ov.w > v.w) { v.w = ov.w; a.w = oa.w; }
+            }
+            *reinterpret_cast<float4*>(cmax_v + ((size_t)f * nst + st) * L.n2p + j) = v;
+            *reinterpret_cast<int4*>(cmax_i + ((size_t)f * nst + st) * L.n2p + j) = a;
         }
     }
 }
 
-// max0 / indices0 (per query, over n2) and indices1 (per 3D point, over n1)   GATs_SuperGlue.py:220-221
-// 64 outputs x 16 partial-ranges per block; partials are ordered by increasing index, ranges are
-// scanned and combined in order with a strict '>' so the first arg-max wins.
-__global__ __launch_bounds__(1024) void match_reduce_kernel(const float* __restrict__ rmax_v, const int* __restrict__ rmax_i,
-                                                            const float* __restrict__ cmax_v, const int* __restrict__ cmax_i,
-                                                            float* __restrict__ max0, int* __restrict__ idx0,
-                                                            int* __restrict__ idx1, ColLayout L, int nch, int nst) {
-    __shared__ float rv[16][64];
-    __shared__ int ri[16][64];
-    const int f = blockIdx.y, el = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int nrb = L.n1p / 64;
-    const bool rows = (int)blockIdx.x < nrb;
-    const int idx = (rows ? blockIdx.x : blockIdx.x - nrb) * 64 + el;
-    const int T = rows ? nch : nst;
-    const size_t stride = rows ? L.n1p : L.n2p;
-    const float* pv = (rows ? rmax_v : cmax_v) + (size_t)f * T * stride + idx;
-    const int* pi = (rows ? rmax_i : cmax_i) + (size_t)f * T * stride + idx;
-    const bool live = idx < (rows ? L.n1 : L.n2);
-    const int per = (T + 15) / 16;
-    const int tb = part * per, te = min(T, tb + per);
-    float v = -INFINITY;
-    int a = 0;
-    if (live) {
-#pragma unroll 4
-        for (int t = tb; t < te; ++t) {
-            const float cv = pv[(size_t)t * stride];
-            const int ci = pi[(size_t)t * stride];
-            if (cv > v) { v = cv; a = ci; }
-        }
-    }
-    rv[part][el] = v;
-    ri[part][el] = a;
-    __syncthreads();
-    if (part == 0 && live) {
-        v = rv[0][el];
-        a = ri[0][el];
-#pragma unroll
-        for (int p = 1; p < 16; ++p)
-            if (rv[p][el] > v) { v = rv[p][el]; a = ri[p][el]; }
-        if (rows) {
-            max0[(size_t)f * L.n1p + idx] = v;
-            idx0[(size_t)f * L.n1p + idx] = a;
-        } else {
-            idx1[(size_t)f * L.n2p + idx] = a;
-        }
-    }
-}
-
-// mutual check, threshold, -1 fill                                       GATs_SuperGlue.py:222-237
-__global__ __launch_bounds__(256) void match_tail_kernel(const float* __restrict__ max0, const int* __restrict__ idx0,
-                                                         const int* __restrict__ idx1, float thr,
-                                                         int64_t* __restrict__ matches0, int64_t* __restrict__ matches1,
-                                                         float* __restrict__ ms0, float* __restrict__ ms1, ColLayout L) {
+// mutual check, threshold, -1 fill (GATs_SuperGlue.py:220-237) straight from the finalize kernel's partials: the row
+// (max, arg-max) of query i is the first maximum over its nch chunk partials, the column arg-max of 3D point j the first
+// maximum over its nst strip partials (partials are ordered by increasing index; strict '>' keeps the first).
+//   row thread i:    j = argmax_j conf[i, :];  mutual0 = argmax_i conf[:, j] == i
+//   column thread j: i = argmax_i conf[:, j];  mutual1 = argmax_j conf[i, :] == j   (which implies mutual0 of i)
+__global__ __launch_bounds__(256) void match_tail_kernel(const float* __restrict__ rmax_v, const int* __restrict__ rmax_i,
+                                                         const float* __restrict__ cmax_v, const int* __restrict__ cmax_i,
+                                                         float thr, int64_t* __restrict__ matches0,
+                                                         int64_t* __restrict__ matches1, float* __restrict__ ms0,
+                                                         float* __restrict__ ms1, ColLayout L, int nch, int nst) {
     const int f = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int* i0 = idx0 + (size_t)f * L.n1p;
-    const int* i1 = idx1 + (size_t)f * L.n2p;
-    const float* m0 = max0 + (size_t)f * L.n1p;
+    const float* rv = rmax_v + (size_t)f * nch * L.n1p;
+    const int* ri = rmax_i + (size_t)f * nch * L.n1p;
+    const float* cv = cmax_v + (size_t)f * nst * L.n2p;
+    const int* ci = cmax_i + (size_t)f * nst * L.n2p;
+    auto rowarg = [&](int i, float& v) {
+        v = -INFINITY;
+        int a = 0;
+        for (int c = 0; c < nch; ++c) {
+            const float x = rv[(size_t)c * L.n1p + i];
+            if (x > v) { v = x; a = ri[(size_t)c * L.n1p + i]; }
+        }
+        return a;
+    };
+    auto colarg = [&](int j) {
+        float v = -INFINITY;
+        int a = 0;
+#pragma unroll 8
+        for (int t = 0; t < nst; ++t) {
+            const float x = cv[(size_t)t * L.n2p + j];
+            const int xi = ci[(size_t)t * L.n2p + j];
+            if (x > v) { v = x; a = xi; }
+        }
+        return a;
+    };
     if (idx < L.n1) {
-        const int j = i0[idx];
-        const bool mutual0 = i1[j] == idx;
-        const float s0 = mutual0 ? m0[idx] : 0.f;
+        float v;
+        const int j = rowarg(idx, v);
+        const bool mutual0 = colarg(j) == idx;
+        const float s0 = mutual0 ? v : 0.f;
         const bool valid0 = mutual0 && s0 > thr;
         matches0[(size_t)f * L.n1 + idx] = valid0 ? (int64_t)j : (int64_t)-1;
         ms0[(size_t)f * L.n1 + idx] = s0;
     } else if (idx >= L.n1p && idx - L.n1p < L.n2) {
         const int j = idx - L.n1p;
-        const int i = i1[j];
-        const bool mutual1 = i0[i] == j;
-        const bool mutual0_i = i1[i0[i]] == i;
-        const float s0_i = mutual0_i ? m0[i] : 0.f;
-        const float s1 = mutual1 ? s0_i : 0.f;
-        const bool valid1 = mutual1 && (mutual0_i && s0_i > thr);
+        const int i = colarg(j);
+        float v;
+        const bool mutual1 = rowarg(i, v) == j;
+        const float s1 = mutual1 ? v : 0.f;
+        const bool valid1 = mutual1 && v > thr;
         matches1[(size_t)f * L.n2 + j] = valid1 ? (int64_t)i : (int64_t)-1;
         ms1[(size_t)f * L.n2 + j] = s1;
     }
 }
 
-void launch_dual_softmax_match(const Workspace& w, float* conf, float thr, int64_t* matches0, int64_t* matches1,
-                               float* mscores0, float* mscores1, hipStream_t s, ProfileHook* hk) {
-    const ColLayout& L = w.L;
-    const dim3 g1((L.n1p + L.n2p + 255) / 256, L.b);
-    const dim3 g64((L.n1p + L.n2p) / 64, L.b);
-    GATSSPG_LAUNCH(hk, KID_SOFTMAX_SUMS, s, softmax_sums_kernel, g64, dim3(1024), 0, s, w.rowpart, w.colpart, w.rs, w.cs, L,
-                   w.sc_nct, w.sc_nrt);
-    if ((L.n2 & 3) == 0 && (reinterpret_cast<uintptr_t>(conf) & 15) == 0) {
-        GATSSPG_LAUNCH(hk, KID_CONF_FINALIZE, s, conf_finalize_kernel<true>, dim3(w.cf_nch, w.cf_nst, L.b), dim3(256), 0, s,
-                       conf, w.rs, w.cs, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, L, w.cf_nch, w.cf_nst);
-    } else {
-        GATSSPG_LAUNCH(hk, KID_CONF_FINALIZE, s, conf_finalize_kernel<false>, dim3(w.cf_nch, w.cf_nst, L.b), dim3(256), 0, s,
-                       conf, w.rs, w.cs, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, L, w.cf_nch, w.cf_nst);
+// ---- max-subtracting softmax statistics of the raw score matrix S (only when 1 / scale_factor > 80; off the benchmarked
+//      path, simple kernels): per row i  rshift = max_j S_ij, rs = sum_j exp(S_ij - rshift); per column likewise ----
+__global__ __launch_bounds__(256) void softmax_rowstat_kernel(const float* __restrict__ S, float* __restrict__ rshift,
+                                                              float* __restrict__ rs, ColLayout L) {
+    __shared__ float red[256];
+    const int i = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const float* row = S + ((size_t)f * L.n1 + i) * L.n2;
+    float m = -INFINITY;
+    for (int j = tid; j < L.n2; j += 256) m = fmaxf(m, row[j]);
+    red[tid] = m;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        __syncthreads();
     }
-    GATSSPG_LAUNCH(hk, KID_MATCH_REDUCE, s, match_reduce_kernel, g64, dim3(1024), 0, s, w.rmax_v, w.rmax_i, w.cmax_v,
-                   w.cmax_i, w.max0, w.idx0, w.idx1, L, w.cf_nch, w.cf_nst);
-    GATSSPG_LAUNCH(hk, KID_MATCH_TAIL, s, match_tail_kernel, g1, dim3(256), 0, s, w.max0, w.idx0, w.idx1, thr, matches0,
-                   matches1, mscores0, mscores1, L);
+    m = red[0];
+    __syncthreads();
+    float s = 0.f;
+    for (int j = tid; j < L.n2; j += 256) s += expf(row[j] - m);
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {   // fixed tree
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        rshift[(size_t)f * L.n1p + i] = m;
+        rs[(size_t)f * L.n1p + i] = red[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_colstat_kernel(const float* __restrict__ S, float* __restrict__ cshift,
+                                                              float* __restrict__ cs, ColLayout L) {
+    const int j = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (j >= L.n2) return;
+    const float* col = S + (size_t)f * L.n1 * L.n2 + j;
+    float m = -INFINITY;
+    for (int i = 0; i < L.n1; ++i) m = fmaxf(m, col[(size_t)i * L.n2]);
+    float s = 0.f;
+    for (int i = 0; i < L.n1; ++i) s += expf(col[(size_t)i * L.n2] - m);
+    cshift[(size_t)f * L.n2p + j] = m;
+    cs[(size_t)f * L.n2p + j] = s;
+}
+
+void launch_dual_softmax_match(const Workspace& w, float* conf, float scale, int shifted, float thr, int64_t* matches0,
+                               int64_t* matches1, float* mscores0, float* mscores1, hipStream_t s, ProfileHook* hk) {
+    const ColLayout& L = w.L;
+    (void)scale;
+    const dim3 gf(w.cf_nch, w.cf_nst, L.b);
+    const bool vec = (L.n2 & 3) == 0 && (reinterpret_cast<uintptr_t>(conf) & 15) == 0;
+    if (shifted) {
+        GATSSPG_LAUNCH(hk, KID_SOFTMAX_STATS, s, softmax_rowstat_kernel, dim3(L.n1, L.b), dim3(256), 0, s, conf, w.rshift, w.rs, L);
+        GATSSPG_LAUNCH(hk, KID_SOFTMAX_STATS, s, softmax_colstat_kernel, dim3((L.n2 + 255) / 256, L.b), dim3(256), 0, s, conf,
+                       w.cshift, w.cs, L);
+    }
+#define GATSSPG_FINALIZE(VEC_, SH_)                                                                                          \
+    GATSSPG_LAUNCH(hk, KID_CONF_FINALIZE, s, (conf_finalize_kernel<VEC_, SH_>), gf, dim3(256), 0, s, conf, w.rowpart,         \
+                   w.colpart, w.rs, w.cs, w.rshift, w.cshift, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, L, w.sc_nct, w.sc_nrt,  \
+                   w.cf_nch, w.cf_nst)
+    if (vec && !shifted) GATSSPG_FINALIZE(true, false);
+    else if (!shifted) GATSSPG_FINALIZE(false, false);
+    else if (vec) GATSSPG_FINALIZE(true, true);
+    else GATSSPG_FINALIZE(false, true);
+#undef GATSSPG_FINALIZE
+    const dim3 g1((L.n1p + L.n2p + 255) / 256, L.b);
+    GATSSPG_LAUNCH(hk, KID_MATCH_TAIL, s, match_tail_kernel, g1, dim3(256), 0, s, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, thr,
+                   matches0, matches1, mscores0, mscores1, L, w.cf_nch, w.cf_nst);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -292,102 +292,121 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
 }
 
 // =====================================================================================================
-// Split-bf16 variant of the main loop ("bf16x3"): fp32 operands in HBM, each split on the LDS write into two bf16 terms
-// x = x1 + x2 (x1 = RNE_bf16(x), x2 = RNE_bf16(x - x1)); the product is a1*b1 + a1*b2 + a2*b1 on
+// Split-bf16 variant of the main loop ("bf16x3", selected per call by GATSSPG_FLAG_PREC_BF16X3): every fp32 operand is
+// x = x1 + x2 with x1 = RNE_bf16(x), x2 = RNE_bf16(x - x1); the product is a1*b1 + a1*b2 + a2*b1 on
 // v_mfma_f32_32x32x16_bf16 with fp32 accumulation (3 x 32 cycles per 32x32x16 block instead of 8 x 64 for the f32 MFMA).
-// tests/studies/split_bf16_study.py: conf within 5e-7 of the fp32 forward and every match identical at the headline
-// shape.  OPT-IN (GATSSPG_MLP0_PREC=bf16x3): the default path stays exact fp32.
-// LDS images (bf16): A planes [BM][40] (k contiguous, 80-byte rows: 16-byte fragment reads), B planes [BN][40] (the
-// [K][N] activation slab is transposed on the write so that a lane's 8 k values are contiguous).
-// Same pipeline as gemm_mainloop_ex: two register sets, prefetch distance 2, one barrier per slab.
+// tests/studies/split_bf16_study.py: conf within 5e-7 of the fp32 forward and every match identical at the headline shape.
+//   A (weights): split ONCE at pack time into two bf16 planes [M][K] (gatsspg_pack_weights); a slab is copied
+//     global -> LDS as 16-byte pieces, no VALU work.
+//   B (activations, fp32 [K][N] in HBM): a thread owns ONE column and KPT = 4 or 8 consecutive k rows of the slab
+//     (dword loads, coalesced across the wave), applies the optional per-row transform, splits with v_cvt_pk_bf16_f32
+//     and writes its k run of both planes with one 8- or 16-byte LDS store each.
+// LDS images (bf16): A planes [BM][40], B planes [BN][40] (k contiguous, 80-byte rows: the 16-byte fragment reads of
+// 16 consecutive rows hit 16 distinct 4-bank groups).  Pipeline as in gemm_mainloop_ex: two register sets, prefetch
+// distance 2, one barrier per slab.
 // =====================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned bf16_rne_bits(float x) {
     const unsigned u = __float_as_uint(x);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
-__device__ __forceinline__ void bf16_split(float x, unsigned short& hi, unsigned short& lo) {
-    const unsigned h = bf16_rne_bits(x);
-    hi = (unsigned short)h;
-    lo = (unsigned short)bf16_rne_bits(x - __uint_as_float(h << 16));
+// two floats -> packed (hi-term) bf16 pair and packed (lo-term) bf16 pair; element 0 in the low half
+__device__ __forceinline__ void bf16_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const bf16x2 h = __builtin_convertvector((f32x2){a, b}, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xFFFF0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){ra, rb}, bf16x2));
 }
 
 template <class T>
 struct Bf3Layout {
-    static constexpr int KS = 40;                                   // bf16 per row (32 + 8 pad)
-    static constexpr int A_PLANE = T::BM * KS, B_PLANE = T::BN * KS;   // in bf16 elements
-    static constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;         // hi + lo of both operands
-    static constexpr size_t SMEM_BYTES = 2 * (size_t)STAGE * 2;     // two stages
+    static constexpr int KS = 40;                                       // bf16 per LDS row (32 + 8 pad)
+    static constexpr int A_PLANE = T::BM * KS, B_PLANE = T::BN * KS;    // in bf16 elements
+    static constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;             // hi + lo of both operands
+    static constexpr size_t SMEM_BYTES = 2 * (size_t)STAGE * 2;         // two stages
+    static constexpr int A_PIECES = T::BM * 4 * 2 / T::THREADS;         // 16-byte pieces per thread per slab (both planes)
+    static constexpr int KPT = BK * T::BN / T::THREADS;                 // consecutive k rows per thread (one B column)
+    static_assert(KPT == 4 || KPT == 8, "a thread owns 4 or 8 consecutive k of one column");
+    static_assert(A_PIECES >= 1 && ((T::BM * 4) % T::THREADS == 0 || T::THREADS % (T::BM * 4) == 0), "A plane of a piece is static");
+    static_assert(T::BN % 64 == 0, "a wave covers 64 consecutive columns of one k group");
 };
 
-// x_mean / x_rstd / bxform: as in gemm_mainloop_ex (per-k-row aux values, applied to the B registers before the split).
-template <class T, class ASlab, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX>
-__device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, ASlab a_slab,
+// a_hi(kt) / a_lo(kt): bf16 plane pointers of A slab kt (&A[row0][kt*32], row stride lda elements).
+// b_slab(kt): fp32 pointer &B[kt*32][col0], row stride ldb.  x_mean / x_rstd / bxform: per-k-row aux values applied to
+// the B values before the split (mlp.3: InstanceNorm + ReLU on the operand load).
+template <class T, class AHi, class ALo, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX>
+__device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, AHi a_hi, ALo a_lo,
                                                      int lda, BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform) {
     static_assert(!T::AKM && !T::BU, "row-major A, aligned B");
     using LY = Bf3Layout<T>;
-    constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN, KS = LY::KS;
+    constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN, KS = LY::KS, AP = LY::A_PIECES, KPT = LY::KPT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN;
     const int half = lane >> 5, l31 = lane & 31;
-    unsigned a_goff[T::A_VEC], b_goff[T::B_VEC];
-    int a_soff[T::A_VEC], b_sk[T::B_VEC], b_sc[T::B_VEC];
+    // A pieces: idx -> (plane, row, 8-element group); the plane of piece p is a compile-time constant
+    unsigned a_goff[AP];
+    int a_soff[AP];
 #pragma unroll
-    for (int p = 0; p < T::A_VEC; ++p) {
+    for (int p = 0; p < AP; ++p) {
         const int idx = p * T::THREADS + tid;
-        const int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
-        a_goff[p] = 4u * (unsigned)(r * lda + c);
-        a_soff[p] = r * KS + c;
+        const int rem = idx % (BM * 4), r = rem >> 2, c8 = rem & 3;
+        a_goff[p] = 2u * (unsigned)(r * lda + c8 * 8);
+        a_soff[p] = r * KS + c8 * 8;
     }
+    // B: one column, KPT consecutive k; the k group is wave-uniform (BN is a multiple of 64)
+    const int bcol = tid % BN;
+    const int k0 = __builtin_amdgcn_readfirstlane(tid / BN) * KPT;
+    unsigned b_goff[KPT];
 #pragma unroll
-    for (int p = 0; p < T::B_VEC; ++p) {
-        const int idx = p * T::THREADS + tid;
-        const int k = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
-        b_goff[p] = 4u * (unsigned)(k * ldb + c);
-        b_sk[p] = k;
-        b_sc[p] = c;
-    }
-    vf4 ra0[T::A_VEC], rb0[T::B_VEC], ra1[T::A_VEC], rb1[T::B_VEC];
-    float2 rx0[T::B_VEC], rx1[T::B_VEC];
-    auto gload = [&](int kt, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC], float2(&rx)[T::B_VEC]) {
+    for (int j = 0; j < KPT; ++j) b_goff[j] = 4u * (unsigned)((k0 + j) * ldb + bcol);
+    const int b_soff = bcol * KS + k0;
+
+    u32x4 ra0[AP], ra1[AP];
+    float rb0[KPT], rb1[KPT];
+    float2 rx0[KPT], rx1[KPT];
+    auto gload = [&](int kt, u32x4(&ra)[AP], float(&rb)[KPT], float2(&rx)[KPT]) {
 #pragma unroll
-        for (int q = 0; q < T::A_VEC; ++q) ra[q] = ldg4_off(a_slab(kt), a_goff[q]);
+        for (int p = 0; p < AP; ++p) {
+            const bool lo = (p * T::THREADS) / (BM * 4) != 0;
+            const unsigned short* base = lo ? a_lo(kt) : a_hi(kt);
+            ra[p] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + a_goff[p]);
+        }
+        const float* bb = b_slab(kt);
 #pragma unroll
-        for (int q = 0; q < T::B_VEC; ++q) {
-            rb[q] = ldg4_off(b_slab(kt), b_goff[q]);
-            if constexpr (HAS_AUX) rx[q] = make_float2(x_mean(kt)[b_sk[q]], x_rstd(kt)[b_sk[q]]);
+        for (int j = 0; j < KPT; ++j) {
+            rb[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(bb) + b_goff[j]);
+            if constexpr (HAS_AUX) rx[j] = make_float2(x_mean(kt)[k0 + j], x_rstd(kt)[k0 + j]);
         }
     };
-    auto swrite = [&](unsigned short* stage, const vf4(&ra)[T::A_VEC], const vf4(&rb)[T::B_VEC], const float2(&rx)[T::B_VEC]) {
-        unsigned short* Ahi = stage;
-        unsigned short* Alo = stage + LY::A_PLANE;
+    auto swrite = [&](unsigned short* stage, const u32x4(&ra)[AP], const float(&rb)[KPT], const float2(&rx)[KPT]) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            const bool lo = (p * T::THREADS) / (BM * 4) != 0;
+            *reinterpret_cast<u32x4*>(stage + (lo ? LY::A_PLANE : 0) + a_soff[p]) = ra[p];
+        }
         unsigned short* Bhi = stage + 2 * LY::A_PLANE;
         unsigned short* Blo = Bhi + LY::B_PLANE;
+        unsigned h[KPT / 2], l[KPT / 2];
 #pragma unroll
-        for (int p = 0; p < T::A_VEC; ++p) {
-            u16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned short hh, ll;
-                bf16_split(ra[p][e], hh, ll);
-                h[e] = hh; l[e] = ll;
+        for (int j = 0; j < KPT; j += 2) {
+            float v0 = rb[j], v1 = rb[j + 1];
+            if constexpr (HAS_AUX) {
+                v0 = bxform(v0, rx[j]);
+                v1 = bxform(v1, rx[j + 1]);
             }
-            *reinterpret_cast<u16x4*>(Ahi + a_soff[p]) = h;      // 4 consecutive k of one row: 8-byte stores
-            *reinterpret_cast<u16x4*>(Alo + a_soff[p]) = l;
+            bf16_split2(v0, v1, h[j / 2], l[j / 2]);
         }
-#pragma unroll
-        for (int p = 0; p < T::B_VEC; ++p) {
-            vf4 v = rb[p];
-            if constexpr (HAS_AUX) bxform(v, rx[p]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {                         // transpose: column c + e, row k
-                unsigned short hh, ll;
-                bf16_split(v[e], hh, ll);
-                Bhi[(b_sc[p] + e) * KS + b_sk[p]] = hh;
-                Blo[(b_sc[p] + e) * KS + b_sk[p]] = ll;
-            }
+        if constexpr (KPT == 8) {
+            *reinterpret_cast<u32x4*>(Bhi + b_soff) = (u32x4){h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<u32x4*>(Blo + b_soff) = (u32x4){l[0], l[1], l[2], l[3]};
+        } else {
+            *reinterpret_cast<u32x2*>(Bhi + b_soff) = (u32x2){h[0], h[1]};
+            *reinterpret_cast<u32x2*>(Blo + b_soff) = (u32x2){l[0], l[1]};
         }
     };
     auto compute = [&](const unsigned short* stage) {
@@ -429,8 +448,8 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
     gload(min(1, last), ra0, rb0, rx0);
     gload(min(2, last), ra1, rb1, rx1);
     __syncthreads();
-    // step i: MFMAs of slab i, then slab i+1 (in registers since step i-2) is split and written to the free buffer and the
-    // freed registers start loading slab i+3 (issuing the writes / loads before the MFMAs measured no better: 36.0 vs 34.9 us)
+    // step i: MFMAs of slab i, slab i+1 (in registers since step i-2) is split and written to the free buffer, the freed
+    // registers start loading slab i+3
     for (int i = 0; i < KT; i += 2) {
         compute(buf0);
         swrite(buf1, ra0, rb0, rx0);
@@ -445,12 +464,15 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
     }
 }
 
-template <class T, class ASlab, class BSlab>
-__device__ __forceinline__ void gemm_mainloop_bf3(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, ASlab a_slab, int lda,
-                                                  BSlab b_slab, int ldb) {
+struct NoXform1 {
+    __device__ __forceinline__ float operator()(float v, float2) const { return v; }
+};
+template <class T, class AHi, class ALo, class BSlab>
+__device__ __forceinline__ void gemm_mainloop_bf3(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, AHi a_hi, ALo a_lo,
+                                                  int lda, BSlab b_slab, int ldb) {
     auto nox = [](int) { return static_cast<const float*>(nullptr); };
-    gemm_mainloop_bf3_ex<T, ASlab, BSlab, decltype(nox), decltype(nox), NoXform, false>(acc, smem, KT, a_slab, lda, b_slab, ldb, nox,
-                                                                                       nox, NoXform());
+    gemm_mainloop_bf3_ex<T, AHi, ALo, BSlab, decltype(nox), decltype(nox), NoXform1, false>(acc, smem, KT, a_hi, a_lo, lda, b_slab,
+                                                                                          ldb, nox, nox, NoXform1());
 }
 
 // convenience wrapper without per-row aux / transform

@@ -313,6 +313,16 @@ void launch_pack_weights(const void* raw_host, float* packed, hipStream_t s) {
 // =====================================================================================================
 // launchers
 // =====================================================================================================
+// Tuning knobs: the product library never reads the environment; a -DSPP_TUNING build (build_ext --tuning) does.
+static const char* tuning_env(const char* name) {
+#ifdef SPP_TUNING
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 using Tile64x128 = GemmTile<64, 128, 1, 4, false, true>;
 using Tile64x64 = GemmTile<64, 64, 2, 2, false, true>;
 using Tile128x64 = GemmTile<128, 64, 2, 2, false, true>;
@@ -320,7 +330,7 @@ using Tile64x128w8 = GemmTile<64, 128, 2, 4, false, true>;    // 8 waves, one 32
 using Tile128x64w8 = GemmTile<128, 64, 4, 2, false, true>;
 
 static bool patch_tiling() {
-    static const bool on = !(getenv("SPP_PATCH") && atoi(getenv("SPP_PATCH")) == 0);   // SPP_PATCH=0: flat tiles (A/B timing)
+    static const bool on = !(tuning_env("SPP_PATCH") && atoi(tuning_env("SPP_PATCH")) == 0);   // SPP_PATCH=0: flat tiles (A/B timing)
     return on;
 }
 
@@ -352,7 +362,7 @@ static const int* conv_tiles() {
     static bool init = false;
     if (!init) {
         init = true;
-        if (const char* e = getenv("SPP_TILES")) {
+        if (const char* e = tuning_env("SPP_TILES")) {
             int i = 0;
             for (const char* p = e; *p && i < NGEMM; ++p)
                 if (*p >= '0' && *p <= '4') tiles[i++] = *p - '0';
@@ -384,14 +394,14 @@ static void launch_pool(const float* X, const FeatLayout& Li, float* Y, const Fe
 template <int CIN>
 static void launch_conv_pool(int gi, int kid, const float* packed, const float* X, float* tmp, float* Y2, const FeatLayout& L,
                              const FeatLayout& L2, hipStream_t s, ProfileHook* hk) {
-    static const bool fuse = !(getenv("SPP_FUSE_POOL") && atoi(getenv("SPP_FUSE_POOL")) == 0);
+    static const bool fuse = !(tuning_env("SPP_FUSE_POOL") && atoi(tuning_env("SPP_FUSE_POOL")) == 0);
     const int cout = kConv[gi].cout;
     if (!fuse) {
         launch_conv<CIN, 9>(gi, kid, packed, X, tmp, L, 1, s, hk);
         launch_pool(tmp, L, Y2, L2, cout, s, hk);
         return;
     }
-    static const bool w8 = getenv("SPP_POOL_TILE") && atoi(getenv("SPP_POOL_TILE")) == 1;   // 1: the 64x128 patch on 8 waves
+    static const bool w8 = tuning_env("SPP_POOL_TILE") && atoi(tuning_env("SPP_POOL_TILE")) == 1;   // 1: the 64x128 patch on 8 waves
     const int NT = L.b * (L.H / 2) * ((L.W + 63) / 64);
     auto go = [&](auto kern, int threads, size_t lds) {
         SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(cout / 64, NT)), dim3(threads), lds, s, packed + conv_w_off(gi),

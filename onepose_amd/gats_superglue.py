@@ -99,24 +99,27 @@ class KeypointEncoder(nn.Module):
             raise NotImplementedError("HIP KeypointEncoder supports the shipped layout [inp,32,64,128,256]")
         lib = _native.load()
         kpts = _require_gpu(kpts.float().contiguous(), "kpts")
-        scores = scores.float().contiguous()
+        scores = _require_gpu(scores.float().contiguous(), "scores")
+        if scores.device != kpts.device:
+            raise RuntimeError(f"kpts is on {kpts.device} but scores is on {scores.device}")
         b, n = kpts.shape[0], kpts.shape[1]
         if n < 2:
             raise ValueError(f"Expected more than 1 spatial element when training, got input size {[b, 32, n]}")
         kw = _native.KencWeights()
         keep = []
         for j, idx in enumerate((0, 3, 6, 9)):
-            w = self.encoder[idx].weight.detach().float().contiguous()
-            bb = self.encoder[idx].bias.detach().float().contiguous()
+            w = _require_gpu(self.encoder[idx].weight.detach().float().contiguous(), "encoder weight")
+            bb = _require_gpu(self.encoder[idx].bias.detach().float().contiguous(), "encoder bias")
             keep += [w, bb]
             kw.w[j], kw.b[j] = w.data_ptr(), bb.data_ptr()
         kw.inp_dim = self.inp_dim
-        out = torch.empty(b, D, n, device=kpts.device, dtype=torch.float32)
-        nbytes = lib.gatsspg_kenc_scratch_bytes(b, n)
-        scratch = torch.empty(nbytes, device=kpts.device, dtype=torch.uint8)
-        _native.check(lib.gatsspg_keypoint_encoder(ctypes.byref(kw), kpts.data_ptr(), scores.data_ptr(), b, n,
-                                                   out.data_ptr(), scratch.data_ptr(), nbytes, _stream(kpts.device)),
-                      "gatsspg_keypoint_encoder")
+        with torch.cuda.device(kpts.device):   # the C ABI launches on the CURRENT device: make it the tensors' device
+            out = torch.empty(b, D, n, device=kpts.device, dtype=torch.float32)
+            nbytes = lib.gatsspg_kenc_scratch_bytes(b, n)
+            scratch = torch.empty(nbytes, device=kpts.device, dtype=torch.uint8)
+            _native.check(lib.gatsspg_keypoint_encoder(ctypes.byref(kw), kpts.data_ptr(), scores.data_ptr(), b, n,
+                                                       out.data_ptr(), scratch.data_ptr(), nbytes, _stream(kpts.device)),
+                          "gatsspg_keypoint_encoder")
         return out
 
 
@@ -145,15 +148,43 @@ class Database:
             raise ValueError(f"database cache was built for b={self.b} n2={self.n2} num_leaf={self.num_leaf} on "
                              f"{self.cache.device}; got b={b} n2={n2} num_leaf={num_leaf} on {device}")
         engine.packed_weights(device)
-        if engine._packed_key != self.weights_key:
-            raise ValueError("database cache was built with different weights; call prepare_database again")
+        if (engine._packed_key, engine.flags()) != self.weights_key:
+            raise ValueError("database cache was built with different weights / flags / precision; call prepare_database again")
 
 
 # --------------------------------------------------------------------------------------------------
 # the engine: packed weights + workspace + stage calls (also used by the per-kernel parity tests)
 # --------------------------------------------------------------------------------------------------
+def _on_device(fn):
+    """Run an engine method with the CURRENT HIP device set to the device of its first tensor argument / `dims`: the
+    C ABI takes a stream handle but launches (and sets kernel attributes) on the current device, so
+    ``model.to('cuda:1')(inputs)`` must not depend on the caller having called ``torch.cuda.set_device(1)``."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        dev = None
+        for a in args:
+            if torch.is_tensor(a):
+                dev = a.device
+                break
+            if isinstance(a, tuple) and a and isinstance(a[-1], torch.device):
+                dev = a[-1]
+                break
+        if dev is None or dev.type != "cuda":
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+    return wrapper
+
+
 class GATsSPGEngine:
-    """Owns the device-side packed weights and workspaces of one module on one device."""
+    """Owns the device-side packed weights and workspaces of one module on one device.
+
+    Workspaces are cached per (shape, device, STREAM): two forwards of one module on two streams never share scratch
+    (Z / Q / MSG / U live there), so concurrent use of a module from several streams is safe."""
+
+    MAX_CACHED_WORKSPACES = 8
 
     def __init__(self, module):
         self.module = module
@@ -202,21 +233,22 @@ class GATsSPGEngine:
                 ai += 1
         raw.final_w, raw.final_b = next(it).data_ptr(), next(it).data_ptr()
         packed = torch.empty(self.lib.gatsspg_packed_weights_bytes() // 4, device=device, dtype=torch.float32)
-        _native.check(self.lib.gatsspg_pack_weights(ctypes.byref(raw), packed.data_ptr(), _stream(device)),
-                      "gatsspg_pack_weights")
+        with torch.cuda.device(device):
+            _native.check(self.lib.gatsspg_pack_weights(ctypes.byref(raw), packed.data_ptr(), _stream(device)),
+                          "gatsspg_pack_weights")
         self._packed, self._packed_key = packed, key
         return packed
 
     # ---- workspace ----
     def workspace(self, b, n1, n2, num_leaf, device):
-        key = (b, n1, n2, num_leaf, str(device))
+        key = (b, n1, n2, num_leaf, str(device), torch.cuda.current_stream(device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None:
             nbytes = self.lib.gatsspg_workspace_bytes(b, n1, n2, num_leaf)
             if nbytes == 0:
                 raise _native.NativeError("gatsspg_workspace_bytes: " + self.lib.gatsspg_last_error().decode())
-            if len(self._ws) >= 4:
-                self._ws.clear()
+            if len(self._ws) >= self.MAX_CACHED_WORKSPACES:
+                self._ws.clear()   # (the caching allocator keeps a dropped buffer alive until its stream is done with it)
             ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
             self._ws[key] = ws
         return ws
@@ -225,9 +257,11 @@ class GATsSPGEngine:
         hp = self.module.hparams
         return ((_native.FLAG_INCLUDE_SELF if hp["include_self"] else 0)
                 | (_native.FLAG_ADDITIONAL if hp["additional"] else 0)
-                | (_native.FLAG_WITH_LINEAR_TRANSFORM if hp["with_linear_transform"] else 0))
+                | (_native.FLAG_WITH_LINEAR_TRANSFORM if hp["with_linear_transform"] else 0)
+                | _native.PRECISIONS[self.module.precision])
 
     # ---- whole forward, all b samples ----
+    @_on_device
     def forward(self, dq, d3, d2db, scale_factor, match_threshold, database=None):
         b, _, n1 = dq.shape
         n2 = d3.shape[2]
@@ -254,6 +288,7 @@ class GATsSPGEngine:
             s1.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "gatsspg_forward")
         return conf, m0, m1, s0, s1
 
+    @_on_device
     def prepare_database(self, d3, d2db):
         """Query-independent part of the first three GNN layers for a resident 3D database (amortised mode)."""
         b, _, n2 = d3.shape
@@ -266,9 +301,10 @@ class GATsSPGEngine:
         _native.check(self.lib.gatsspg_prepare_database(
             packed.data_ptr(), d3.data_ptr(), d2db.data_ptr(), b, n2, num_leaf, self.flags(), cache.data_ptr(), nbytes,
             ws.data_ptr(), ws.numel(), _stream(dev)), "gatsspg_prepare_database")
-        return Database(cache, d3, d2db, b, n2, num_leaf, self._packed_key)
+        return Database(cache, d3, d2db, b, n2, num_leaf, (self._packed_key, self.flags()))
 
     # ---- stages (parity tests) ----
+    @_on_device
     def load_state(self, dq, d3, num_leaf):
         b, _, n1 = dq.shape
         n2 = d3.shape[2]
@@ -277,6 +313,7 @@ class GATsSPGEngine:
                                                   ws.numel(), _stream(dq.device)), "gatsspg_load_state")
         return (b, n1, n2, num_leaf, dq.device)
 
+    @_on_device
     def store_state(self, dims, which=0):
         b, n1, n2, num_leaf, dev = dims
         ws = self.workspace(*dims)
@@ -286,6 +323,7 @@ class GATsSPGEngine:
                                                    ws.data_ptr(), ws.numel(), _stream(dev)), "gatsspg_store_state")
         return o2, o3
 
+    @_on_device
     def gats_layer(self, dims, layer, d2db, flags=None):
         b, n1, n2, num_leaf, dev = dims
         ws = self.workspace(*dims)
@@ -293,18 +331,21 @@ class GATsSPGEngine:
                                                   num_leaf, self.flags() if flags is None else flags, ws.data_ptr(),
                                                   ws.numel(), _stream(dev)), "gatsspg_gats_layer")
 
+    @_on_device
     def attn_layer(self, dims, layer, kind):
         b, n1, n2, num_leaf, dev = dims
         ws = self.workspace(*dims)
         _native.check(self.lib.gatsspg_attn_layer(self.packed_weights(dev).data_ptr(), layer, kind, b, n1, n2, num_leaf,
-                                                  ws.data_ptr(), ws.numel(), _stream(dev)), "gatsspg_attn_layer")
+                                                  self.flags(), ws.data_ptr(), ws.numel(), _stream(dev)), "gatsspg_attn_layer")
 
+    @_on_device
     def final_proj_norm(self, dims):
         b, n1, n2, num_leaf, dev = dims
         ws = self.workspace(*dims)
         _native.check(self.lib.gatsspg_final_proj_norm(self.packed_weights(dev).data_ptr(), b, n1, n2, num_leaf,
                                                        ws.data_ptr(), ws.numel(), _stream(dev)), "gatsspg_final_proj_norm")
 
+    @_on_device
     def score_match(self, dims, scale_factor, match_threshold):
         b, n1, n2, num_leaf, dev = dims
         ws = self.workspace(*dims)
@@ -324,11 +365,18 @@ class GATsSPGEngine:
 # the drop-in module
 # --------------------------------------------------------------------------------------------------
 class GATsSuperGlue(nn.Module):
-    """HIP implementation behind the reference ``GATsSuperGlue`` API (GATs_SuperGlue.py:143-241)."""
+    """HIP implementation behind the reference ``GATsSuperGlue`` API (GATs_SuperGlue.py:143-241).
 
-    def __init__(self, hparams):
+    ``precision`` (keyword-only, not part of the reference signature; also settable as an attribute) selects the
+    arithmetic of the attention layers' GEMMs for every call of this module: ``"fp32"`` (default: exact fp32 MFMA, the
+    reference's arithmetic) or ``"bf16x3"`` (split-bf16 MFMA, three bf16 products per fp32 product; conf within 1e-6 of
+    the fp32 forward and identical matches on every parity case).  It travels to the library as a bit of the ``flags``
+    argument of the C ABI; nothing is read from the environment."""
+
+    def __init__(self, hparams, *, precision="fp32"):
         super().__init__()
         self.hparams = hparams
+        self.precision = precision
         self.match_type = hparams["match_type"]
         if hparams["descriptor_dim"] != D:
             raise NotImplementedError("descriptor_dim must be 256 (the reference GNN hard-codes it, :35-36)")
@@ -339,6 +387,16 @@ class GATsSuperGlue(nn.Module):
         self.final_proj = nn.Conv1d(hparams["descriptor_dim"], hparams["descriptor_dim"], kernel_size=1, bias=True)
         self.register_parameter("bin_score", nn.Parameter(torch.tensor(1.0)))
         self._engine = None
+
+    @property
+    def precision(self):
+        return self._precision
+
+    @precision.setter
+    def precision(self, value):
+        if value not in _native.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_native.PRECISIONS)} (got {value!r})")
+        self._precision = value
 
     @property
     def engine(self):

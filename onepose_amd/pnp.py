@@ -45,9 +45,10 @@ def ransac_pnp_device(K, pts_2d, pts_3d, scale=1.0, reproj_error=REPROJ_ERROR, i
     pose = torch.empty(3, 4, device=dev, dtype=torch.float64)
     mask = torch.zeros(max(n, 1), device=dev, dtype=torch.int32)
     info = torch.zeros(4, device=dev, dtype=torch.int32)
-    _native_pnp.check(lib.pnp_ransac_epnp(p3.data_ptr(), p2.data_ptr(), _k_array(K), float(scale), n, float(reproj_error),
-                                          int(iterations), int(seed), pose.data_ptr(), mask.data_ptr(), info.data_ptr(),
-                                          ws.data_ptr(), ws.numel(), _stream(dev)), "pnp_ransac_epnp")
+    with torch.cuda.device(dev):   # the C ABI launches on the current device
+        _native_pnp.check(lib.pnp_ransac_epnp(p3.data_ptr(), p2.data_ptr(), _k_array(K), float(scale), n, float(reproj_error),
+                                              int(iterations), int(seed), pose.data_ptr(), mask.data_ptr(), info.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), _stream(dev)), "pnp_ransac_epnp")
     return pose, mask[:n], info
 
 
@@ -67,9 +68,10 @@ def ransac_pnp_from_matches(K, kpts2d, kpts3d, matches0, scale=1.0, reproj_error
     pose = torch.empty(3, 4, device=dev, dtype=torch.float64)
     mask = torch.empty(n1, device=dev, dtype=torch.int32)
     info = torch.empty(4, device=dev, dtype=torch.int32)
-    _native_pnp.check(lib.pnp_ransac_epnp_matches(k2.data_ptr(), k3.data_ptr(), m0.data_ptr(), n1, _k_array(K), float(scale),
-                                                  float(reproj_error), int(iterations), int(seed), pose.data_ptr(), mask.data_ptr(),
-                                                  info.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "pnp_ransac_epnp_matches")
+    with torch.cuda.device(dev):
+        _native_pnp.check(lib.pnp_ransac_epnp_matches(k2.data_ptr(), k3.data_ptr(), m0.data_ptr(), n1, _k_array(K), float(scale),
+                                                      float(reproj_error), int(iterations), int(seed), pose.data_ptr(), mask.data_ptr(),
+                                                      info.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "pnp_ransac_epnp_matches")
     return pose, mask, info
 
 
@@ -98,8 +100,9 @@ def epnp(K, pts_2d, pts_3d, scale=1.0):
     p3 = pts_3d.to(torch.float32).contiguous()
     pose = torch.empty(3, 4, device=p2.device, dtype=torch.float64)
     lib = _native_pnp.load()
-    _native_pnp.check(lib.pnp_epnp(p3.data_ptr(), p2.data_ptr(), _k_array(K), float(scale), p2.shape[0], pose.data_ptr(), None, 0,
-                                   _stream(p2.device)), "pnp_epnp")
+    with torch.cuda.device(p2.device):
+        _native_pnp.check(lib.pnp_epnp(p3.data_ptr(), p2.data_ptr(), _k_array(K), float(scale), p2.shape[0], pose.data_ptr(), None, 0,
+                                       _stream(p2.device)), "pnp_epnp")
     return pose
 
 

@@ -29,8 +29,24 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _on_device(fn):
+    """Run an engine method with the CURRENT HIP device set to the device of its first tensor argument (the C ABI takes a
+    stream handle but launches on the current device)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        dev = next((a.device for a in args if torch.is_tensor(a)), None)
+        if dev is None or dev.type != "cuda":
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+    return wrapper
+
+
 class SuperPointEngine:
-    """Owns the packed weights and workspaces of one module on one device."""
+    """Owns the packed weights and workspaces of one module on one device; workspaces are cached per (shape, device,
+    stream), so one module can be used from several streams at once."""
 
     def __init__(self, module):
         self.module = module
@@ -58,26 +74,28 @@ class SuperPointEngine:
         for i in range(_native_spp.NUM_LAYERS):
             raw.weight[i], raw.bias[i] = keep_w[i].data_ptr(), keep_b[i].data_ptr()
         packed = torch.empty(self.lib.spp_packed_weights_bytes() // 4, device=device, dtype=torch.float32)
-        _native_spp.check(self.lib.spp_pack_weights(ctypes.byref(raw), packed.data_ptr(), _stream(device)), "spp_pack_weights")
+        with torch.cuda.device(device):
+            _native_spp.check(self.lib.spp_pack_weights(ctypes.byref(raw), packed.data_ptr(), _stream(device)), "spp_pack_weights")
         # keep_* may be released here: the caching allocator is stream-ordered and the packing kernels were
         # enqueued on this stream
         self._packed, self._packed_key = packed, key
         return packed
 
     def workspace(self, b, h, w, device):
-        key = (b, h, w, str(device))
+        key = (b, h, w, str(device), torch.cuda.current_stream(device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None:
             nbytes = self.lib.spp_workspace_bytes(b, h, w)
             if nbytes == 0:
                 raise NativeError("spp_workspace_bytes: " + self.lib.spp_last_error().decode())
-            if len(self._ws) >= 2:
+            if len(self._ws) >= 6:
                 self._ws.clear()
             ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
             self._ws[key] = ws
         return ws
 
     # ---- stages (tests) ----
+    @_on_device
     def dense(self, image):
         b, _, h, w = image.shape
         dev = image.device
@@ -101,6 +119,7 @@ class SuperPointEngine:
         # -1 = keep everything: NMS survivors are more than `radius` apart (plateaus aside); retried at H*W on overflow
         return mk if mk >= 0 else max(1024, (h * w) // ((cfg["nms_radius"] + 1) ** 2))
 
+    @_on_device
     def detect(self, score, dense, cfg, align_corners, capacity=None, return_nms=False):
         b, h, w = score.shape
         dev = score.device
@@ -114,6 +133,7 @@ class SuperPointEngine:
             nms.data_ptr() if return_nms else None, ws.data_ptr(), ws.numel(), _stream(dev)), "spp_detect")
         return kp, sc, de, cnt, nms
 
+    @_on_device
     def forward(self, image, cfg, align_corners, capacity=None):
         b, _, h, w = image.shape
         dev = image.device

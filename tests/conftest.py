@@ -33,3 +33,49 @@ def case_inputs(meta_case):
     sd = synthetic.make_state_dict(seed) if kind == "random" else synthetic.make_passthrough_state_dict(seed)
     data = synthetic.make_inputs(**meta_case["inputs"])
     return sd, data, meta_case["hparams"]
+
+
+@pytest.fixture(scope="session")
+def bench_golden_meta():
+    with open(os.path.join(GOLDEN_DIR, "bench_golden_meta.json")) as f:
+        return json.load(f)
+
+
+# An arg-max may differ from the reference's only where the reference itself cannot tell the two candidates apart in
+# fp32: the relative gap between its best and second-best entry is below TIE_GAP.  Everything else must be identical.
+TIE_GAP = 2e-5
+
+
+def argmax_flips(idx, ref_idx, ref_gap, what):
+    """Number of arg-max indices that differ from the reference's; raises if one of them is not a near-tie
+    (reference top-2 relative gap >= TIE_GAP).  `ref_gap` is the golden's row/col_top2_rel_gap."""
+    idx, ref_idx = np.asarray(idx), np.asarray(ref_idx)
+    diff = idx != ref_idx
+    n = int(diff.sum())
+    if n:
+        worst = float(np.asarray(ref_gap)[diff].max())
+        assert worst < TIE_GAP, (f"{what}: {n} arg-max indices differ from the reference and at least one is not a "
+                                 f"near-tie (reference top-2 relative gap {worst:.3e} >= {TIE_GAP})")
+    return n
+
+
+def check_bench_golden(cn, pred0, g, meta_case, conf_atol, what, rsum_rtol=2e-3):
+    """Compare a full conf tensor `cn` [b,n1,n2] and sample-0 `pred0` (numpy) against a bench-shape summary golden.
+    conf sub-sample / row+col maxima within `conf_atol`; raw arg-max indices and matches identical (near-ties of the
+    reference excepted, counted and returned)."""
+    rs, cs = meta_case["sub"]
+    md = lambda a, b: float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))  # noqa: E731
+    assert tuple(cn.shape) == tuple(g["conf_shape"])
+    errs = {"sub": md(cn[:, ::rs, ::cs], g["conf_sub"]), "rowmax": md(cn.max(axis=2), g["conf_rowmax"]),
+            "colmax": md(cn.max(axis=1), g["conf_colmax"])}
+    assert max(errs.values()) < conf_atol, f"{what}: conf errors {errs}"
+    np.testing.assert_allclose(cn.sum(axis=2, dtype=np.float64), g["conf_rowsum"], rtol=rsum_rtol, atol=1e-6)
+    np.testing.assert_allclose(cn.sum(axis=1, dtype=np.float64), g["conf_colsum"], rtol=rsum_rtol, atol=1e-6)
+    f0 = argmax_flips(cn.argmax(axis=2), g["indices0_raw"], g["row_top2_rel_gap"], what + " rows")
+    f1 = argmax_flips(cn.argmax(axis=1), g["indices1_raw"], g["col_top2_rel_gap"], what + " cols")
+    if f0 + f1 == 0:
+        np.testing.assert_array_equal(pred0["matches0"], g["matches0"])
+        np.testing.assert_array_equal(pred0["matches1"], g["matches1"])
+        assert int((pred0["matches0"] >= 0).sum()) == meta_case["valid_matches0"]
+    np.testing.assert_allclose(pred0["matching_scores0"], g["matching_scores0"], atol=conf_atol)
+    return {"flips_rows": f0, "flips_cols": f1, **errs}

@@ -14,8 +14,9 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "dtype", "data", "config"}
 
 
-def run(*flags):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=600, cwd=ROOT)
+def run(*flags, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -31,6 +32,34 @@ def test_default_line_contract():
     rf = d["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] == "mfma" and 0.2 < rf["frac"] < 1.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "static" in rf["traffic_source"]
+    # the timed code path reproduces the reference's own output on the golden frame, in the same JSON line
+    pc = d["parity_check"]
+    assert "reference" in pc["against"] and pc["max_abs_conf_err"] < 1e-4 and pc["argmax_flips"] == 0 and pc["argmax_checked"] == 8000
+    assert len(d["config"]["timed_pass_seconds"]) == d["config"]["timed_pass_repetitions"] >= 5
+
+
+@gpu
+def test_split_bf16_batch8_line():
+    """BASELINE configs[2]: its own line, dtype bf16x3, priced against the bf16 peak, never the headline metric config."""
+    d = run("--config", "bf16x3-b8", "--steps", "4", "--warmup", "1", "--reps", "2", "--no-cpu-baseline")
+    assert d["dtype"] == "bf16x3" and d["config"]["batch"] == 8 and d["config"]["name"] == "bf16x3-b8"
+    assert d["roofline"]["peak"] > 2000 and d["parity_check"]["max_abs_conf_err"] < 1e-4 and d["parity_check"]["argmax_flips"] == 0
+
+
+def test_gpus_n_launches_n_ranks_by_itself():
+    """`python bench.py --gpus 2` without a torchrun environment spawns 2 ranks (here: CPU stand-in steps over gloo) and
+    rank 0 prints one line with n_gpus 2; a WORLD_SIZE that contradicts --gpus is refused, never silently used."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = run("--gpus", "2", "--dry-run", "--steps", "10", "--warmup", "1", "--reps", "2", env=env)
+    assert d["n_gpus"] == 2 and d["data"] == "dry-run" and len(d["config"]["per_rank_frames_per_sec"]) == 2
+    bad = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,
+                       timeout=120, cwd=ROOT, env=bad)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=120,
+                       cwd=ROOT, env=env)
+    assert r.returncode != 0 and "refusing" in r.stderr
 
 
 def test_cpu_baseline_legs():
@@ -38,8 +67,8 @@ def test_cpu_baseline_legs():
     sys.path.insert(0, ROOT)
     import bench
     for cb, unit in ((bench.cpu_baseline(max_seconds=0.5), "frames/s"), (bench.spp_cpu_baseline(max_seconds=0.5), "images/s")):
-        assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
-        assert cb["unit"] == unit and cb["cores"] >= 1
+        assert {"value", "unit", "cores", "kind", "sample", "host_cores", "threads_used"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
+        assert cb["unit"] == unit and 1 <= cb["cores"] == cb["threads_used"] <= cb["host_cores"] == os.cpu_count()
 
 
 @gpu

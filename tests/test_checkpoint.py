@@ -46,3 +46,38 @@ def test_read_checkpoint_with_unimportable_hparam_classes(tmp_path):
     sd, hp = read_checkpoint(_fake_ckpt(tmp_path, True))
     assert len(sd) == 123
     assert hp["match_threshold"] == 0.35 and hp["scale_factor"] == 0.07
+
+
+def _omegaconf_like_ckpt(tmp_path, hp):
+    """hyper_parameters pickled the way omegaconf does it: a DictConfig whose ``_content`` maps each key to a VALUE NODE
+    object carrying the value under ``_val`` (both classes unimportable here)."""
+    mod = types.ModuleType("omegaconf_like_pkg2")
+    for cname in ("DictConfig", "AnyNode", "ListConfig"):
+        setattr(mod, cname, type(cname, (object,), {"__module__": "omegaconf_like_pkg2", "__qualname__": cname}))
+    sys.modules["omegaconf_like_pkg2"] = mod
+    try:
+        def node(v):
+            if isinstance(v, list):
+                n = mod.ListConfig()
+                n.__dict__["_content"] = [node(e) for e in v]
+                return n
+            n = mod.AnyNode()
+            n.__dict__["_val"] = v
+            return n
+        cfg = mod.DictConfig()
+        cfg.__dict__["_content"] = {k: node(v) for k, v in hp.items()}
+        sd = {"matcher." + k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(3).items()}
+        path = tmp_path / "GATsSPG_omegaconf.ckpt"
+        torch.save({"state_dict": sd, "hyper_parameters": cfg}, path)
+    finally:
+        del sys.modules["omegaconf_like_pkg2"]
+    return path
+
+
+def test_omegaconf_value_nodes_are_unwrapped_not_defaulted(tmp_path):
+    """Non-default flags wrapped in omegaconf value nodes must reach the module (they used to fall back to the defaults)."""
+    hp = {"descriptor_dim": 256, "keypoints_encoder": [32, 64, 128], "match_type": "softmax", "scale_factor": 0.05,
+          "match_threshold": 0.3, "include_self": False, "additional": True, "with_linear_transform": True}
+    sd, got = read_checkpoint(_omegaconf_like_ckpt(tmp_path, hp))
+    assert len(sd) == 123
+    assert got == hp

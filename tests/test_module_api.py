@@ -84,3 +84,22 @@ def test_synthetic_generators_are_deterministic():
         np.testing.assert_array_equal(a[k], b[k])
     np.testing.assert_allclose(np.linalg.norm(a["descriptors2d_db"], axis=1), 1.0, rtol=1e-5)
     assert a["descriptors2d_db"].shape == (1, 256, 56)
+
+
+def test_precision_is_a_constructor_argument_not_an_environment_variable(monkeypatch):
+    """GEMM arithmetic is selected by the keyword-only `precision=` (-> a bit of the C ABI's `flags`), never by the
+    environment: GATSSPG_PREC in the shell changes nothing."""
+    from onepose_amd import _native
+    monkeypatch.setenv("GATSSPG_PREC", "bf16x3")
+    m = GATsSuperGlue(HP)
+    assert m.precision == "fp32" and m.engine.flags() == _native.FLAG_INCLUDE_SELF
+    b = GATsSuperGlue(HP, precision="bf16x3")
+    assert b.engine.flags() == _native.FLAG_INCLUDE_SELF | _native.FLAG_PREC_BF16X3
+    b.precision = "fp32"
+    assert b.engine.flags() == _native.FLAG_INCLUDE_SELF
+    with pytest.raises(ValueError, match="precision must be one of"):
+        GATsSuperGlue(HP, precision="fp16")
+    with pytest.raises(TypeError):
+        GATsSuperGlue(HP, "bf16x3")        # keyword-only: the positional signature stays the reference's
+    # same parameters in both modes: a reference state_dict loads strictly
+    b.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(0).items()}, strict=True)

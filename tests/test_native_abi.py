@@ -35,9 +35,10 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.gatsspg_version() >= 100
-    assert lib.gatsspg_packed_weights_bytes() == 4 * (8 * (768 * 256 + 768 + 512 * 512 + 512 + 256 * 512 + 256)
-                                                       + 4 * (512 + 256 * 256) + 256 * 256 + 256)
+    assert lib.gatsspg_version() >= 200
+    big = 768 * 256 + 512 * 512 + 256 * 512           # the three big operators of an attention layer
+    assert lib.gatsspg_packed_weights_bytes() == (4 * (8 * (big + 768 + 512 + 256) + 4 * (512 + 256 * 256) + 256 * 256 + 256)
+                                                  + 2 * 2 * 8 * big)   # + their bf16 hi / lo planes
     small = lib.gatsspg_workspace_bytes(1, 500, 2000, 8)
     head = lib.gatsspg_workspace_bytes(1, 1000, 7000, 8)
     assert 0 < small < head < 200 * 2**20
@@ -56,3 +57,20 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_native.NativeError, match="no CPU / PyTorch fallback"):
         _native.load()
+
+
+def test_product_libraries_never_read_the_environment(lib):
+    """Precision and tile shapes are arguments / compile-time constants: the shipped libraries do not even import getenv
+    (a stray GATSSPG_* variable in a user's shell cannot change numerics or code paths)."""
+    import subprocess
+    from onepose_amd import build_ext
+    for path in (build_ext.LIB_PATH, build_ext.SPP_LIB_PATH, build_ext.PNP_LIB_PATH):
+        syms = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+        assert "getenv" not in syms, f"{os.path.basename(path)} imports getenv"
+
+
+def test_tuning_and_profiling_builds_compile():
+    """The -DGATSSPG_TUNING / -DGATSSPG_PROFILING_BUILD variants (tools/ab_tuning.py, tools/trace_mlp0.py) must keep
+    compiling: front-end check of every translation unit with both defines."""
+    from onepose_amd import build_ext
+    build_ext.build(profiling=True, syntax_only=True, verbose=False)

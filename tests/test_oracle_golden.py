@@ -104,3 +104,17 @@ def test_torch_oracle_matches_reference(name, golden_meta):
     np.testing.assert_allclose(conf.numpy(), g["conf"], atol=ATOL_CONF, rtol=RTOL)
     np.testing.assert_array_equal(pred["matches0"].numpy(), g["matches0"])
     np.testing.assert_array_equal(pred["matches1"].numpy(), g["matches1"])
+
+
+@pytest.mark.parametrize("name", ["head_rand", "head_planted", "stress_rand"])
+def test_oracle_matches_reference_at_benchmarked_shapes(name, bench_golden_meta):
+    """The numpy oracle against the reference-run summary goldens at the shapes bench.py measures (1000/7000) and at
+    the stress shape (1000/20000): the GPU tests use the oracle at exactly these sizes, so it is pinned here too."""
+    from conftest import check_bench_golden
+    mc = bench_golden_meta["cases"][name]
+    g = load_golden("bench_" + name)
+    sd, data, hp = case_inputs(mc)
+    pred, conf = orc.forward(sd, data, hp)
+    res = check_bench_golden(conf, pred, g, mc, 5e-6, name, rsum_rtol=1e-4)   # conf up to 0.99: a few fp32 ulps
+    print(name, res)
+    assert res["flips_rows"] + res["flips_cols"] == 0
