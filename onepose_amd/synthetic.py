@@ -206,3 +206,28 @@ def make_pose_pairs(seed=0, n=40):
             pred = np.concatenate([pred, [[0, 0, 0, 1.0]]], 0)
         out.append((pred, gt))
     return out
+
+
+# ---- object annotation files (src/sfm/postprocess/feature_process.py:191-194,357-363) --------------
+def make_annotation(n=50, dim=256, seed=0, max_views=15):
+    """Synthetic content of anno_3d_average.npz / anno_3d_collect.npz / idxs.npy: every 3D point has 1..max_views-1
+    collected per-view descriptors (some fewer than num_leaf = 8, some more), concatenated point after point."""
+    rs = np.random.RandomState(seed)
+    idxs = rs.randint(1, max_views, size=n)
+    k = int(idxs.sum())
+    collect = rs.standard_normal((dim, k)).astype(np.float32)
+    owner = np.repeat(np.arange(n), idxs)
+    avg = np.stack([collect[:, owner == i].mean(axis=1) for i in range(n)], axis=1).astype(np.float32)
+    return {"keypoints3d": (rs.rand(n, 3) - 0.5).astype(np.float32), "idxs": idxs, "owner": owner,
+            "collect_descriptors": collect, "collect_scores": rs.rand(k, 1).astype(np.float32),
+            "avg_descriptors": avg, "avg_scores": rs.rand(n, 1).astype(np.float32)}
+
+
+def write_annotation(dirname, anno):
+    """The three files inference.py:113-115 loads, in the reference's layout."""
+    import os
+    np.savez(os.path.join(dirname, "anno_3d_average.npz"), keypoints3d=anno["keypoints3d"], descriptors3d=anno["avg_descriptors"],
+             scores3d=anno["avg_scores"])
+    np.savez(os.path.join(dirname, "anno_3d_collect.npz"), keypoints3d=anno["keypoints3d"],
+             descriptors3d=anno["collect_descriptors"], scores3d=anno["collect_scores"])
+    np.save(os.path.join(dirname, "idxs.npy"), anno["idxs"])

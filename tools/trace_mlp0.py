@@ -1,8 +1,10 @@
 """Per-workgroup timeline of one mlp0_kernel launch (entry / loop end / exit, CU placement, shader clock).
-Needs a profiling build:  python -m onepose_amd.build_ext --force --profiling   (rebuild without it afterwards)."""
+Needs the profiling build:  python -m onepose_amd.build_ext --force --profiling   (-> lib*_tuning.so; the product library is untouched)."""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from onepose_amd import _native, build_ext
+_native.LIB_PATH = build_ext.tuning_path(build_ext.LIB_PATH)
 import bench
 dev = torch.device("cuda:0")
 w = bench.Weights(dev); r = bench.Runner(dev, w)
