@@ -20,7 +20,7 @@ constexpr int MLP0_BN = 64;   // column tile of the mlp.0 kernel (one InstanceNo
 constexpr int SC_BM = 128;    // score kernel row tile (over n1)
 constexpr int SC_BN = 64;     // score kernel column tile (over n2)
 constexpr int CF_ROWS = 16;   // conf-finalize strip height: 4 waves x 4 rows, all loaded before any is processed
-constexpr int CF_COLS = 1024; // conf-finalize chunk width
+constexpr int CF_COLS = 512;  // conf-finalize chunk width: 2 x 16 B per lane and row
 
 // Activation state: channel-major [channels][ld] fp32; frame f owns columns [f*np, (f+1)*np):
 // its N_2D query points at [0, n1) of that range (padded to n1p), its N_3D points at

@@ -15,8 +15,8 @@ namespace gatsspg {
 //                    this column tile's partial  KV_h[q][d] = sum_m V[q][m] K[d][m],  ksum_h[d].
 //     (GATs_SuperGlue.py:96-99 projections, :71-72 feature map, :77-78 KV and key.sum)
 // =====================================================================================================
-using QkvTileW8 = GemmTile<128, QKV_BN, 4, 2, false>;     // fp32: 8 waves, one 32x32 MFMA tile each (38.0 vs 40.1 us on 4 waves)
-using QkvTileB = GemmTile<128, QKV_BN, 2, 2, false>;      // split-bf16: 4 waves, 64x32 per wave (LDS fragment reads per MFMA 2/3)
+using QkvTileW8 = GemmTile<128, QKV_BN, 4, 2, false>;     // both arithmetics: 8 waves, one 32x32 MFMA tile each (fp32: 38.0 vs 40.1 us on 4 waves)
+using QkvTileB = GemmTile<128, QKV_BN, 2, 2, false>;      // split-bf16 alternative (tuning builds): 4 waves, 64x32 per wave (31.2 vs 24.6 us)
 
 // PREC = 0: exact fp32 MFMA.  PREC = 1: split-bf16 main loop on the pre-split weight planes Whi / Wlo.
 template <class T, int PREC = 0>
@@ -188,9 +188,8 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
 //     (sum u, sum u^2 over the tile's real columns; :126).
 // =====================================================================================================
 // tiles (one InstanceNorm partial per 64-column tile whatever BN is)
-using Mlp0TileW8 = GemmTile<128, MLP0_BN, 4, 2, false>;       // fp32 default: 8 waves, one 32x32 MFMA tile each (43.1 vs 45.0 us on 4 waves)
-using Mlp0TileB = GemmTile<128, MLP0_BN, 2, 2, false>;        // split-bf16: 4 waves, 64x32 per wave
-using Mlp0TileB8 = GemmTile<128, 2 * MLP0_BN, 2, 4, false>;   // split-bf16 alternative (tuning builds): 128x128 on 8 waves
+using Mlp0TileW8 = GemmTile<128, MLP0_BN, 4, 2, false>;       // both arithmetics: 8 waves, one 32x32 MFMA tile each (fp32: 43.1 vs 45.0 us on 4 waves)
+using Mlp0TileB8 = GemmTile<128, 2 * MLP0_BN, 2, 4, false>;   // split-bf16 alternative (tuning builds): 128x128 on 8 waves (kernel -4 %, frames/s equal)
 
 // per-workgroup timeline of mlp0_kernel (tools/trace_mlp0.py): 8 x u64 per workgroup
 // [hw_id, xcc_id, t_entry, shader cycles, t_after_mainloop, t_end, rt, ct], 100 MHz wall clock.
@@ -350,9 +349,8 @@ __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restric
 // K6  mlp.3 with the InstanceNorm + ReLU applied on the B-operand load; the accumulators start from
 //     residual + bias:  Z = (Z + b3) + W3 relu((u - mean) * rstd)      (GATs_SuperGlue.py:126-128, :59,64)
 // =====================================================================================================
-using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;          // fp32 default: 64x64 on 4 waves (504 workgroups)
-using Mlp3TileTallW8 = GemmTile<128, 64, 4, 2, false>;   // fp32 alternative (tuning builds): 128x64 on 8 waves (kernel -6 %, 252 workgroups)
-using Mlp3TileB = GemmTile<128, 64, 2, 2, false>;        // split-bf16: 128x64 on 4 waves, 64x32 per wave
+using Mlp3TileTallW8 = GemmTile<128, 64, 4, 2, false>;   // both arithmetics: 128x64 on 8 waves, 252 workgroups (fp32: 21.3 vs 24.6 us, 938 vs 914 frames/s one at a time)
+using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;          // alternative (tuning builds): 64x64 on 4 waves, 504 workgroups
 
 template <class T, int ABL = 0, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
@@ -476,14 +474,14 @@ __global__ __launch_bounds__(256) void final_proj_norm_kernel(const float* __res
 //     RAW (1 / scale_factor > 80): the scaled scores themselves are written, no sums (max-subtracting path).
 //     A = point-major query descriptors MDT (row-major [n][256]), B = channel-major 3D descriptors MD.
 // =====================================================================================================
-using ScoreTileW8 = GemmTile<SC_BM, SC_BN, 4, 2, false>;    // 128x64 on 8 waves
+using ScoreTileW8 = GemmTile<SC_BM, SC_BN, 4, 2, false>;    // 128x64 on 8 waves (a 256x64 tile -- one round of workgroups instead of 1.7 -- measured slower: 52.7 vs 46.4 us)
 
 template <class T, bool RAW>
 __global__ __launch_bounds__(T::THREADS) void score_exp_kernel(const float* __restrict__ MDT, const float* __restrict__ MD,
                                                                float* __restrict__ conf, float* __restrict__ rowpart,
                                                                float* __restrict__ colpart, ColLayout L, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int nrt = L.n1p / T::BM, nct = L.n2p / T::BN;
+    const int nrt = (L.n1p + T::BM - 1) / T::BM, nct = L.n2p / T::BN;   // a last row tile may hang over n1p (rows masked below)
     int rt, ct;
     const int frame = blockIdx.y;
     if (!xcd_tile_map(nrt, nct, rt, ct)) return;
@@ -541,7 +539,7 @@ __global__ __launch_bounds__(T::THREADS) void score_exp_kernel(const float* __re
         for (int m = 0; m < CPL; ++m) s += tr[m];
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
-        if (hp == 0) rowpart[((size_t)frame * nct + ct) * L.n1p + rt * T::BM + row] = s;
+        if (hp == 0 && rt * T::BM + row < L.n1p) rowpart[((size_t)frame * nct + ct) * L.n1p + rt * T::BM + row] = s;
         constexpr int NQ = T::THREADS / 64, RPQ = T::BM / NQ;
         const int c = tid & 63, qp = tid >> 6;
         float t = 0.f;
@@ -653,7 +651,9 @@ static void launch_qkv_t(const float* Wqkv, const float* bqkv, const unsigned sh
 
 void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s,
                    ProfileHook* hk) {
-    if (w.prec == 1) launch_qkv_t<QkvTileB, 1>(Wqkv, bqkv, wb, w, s, hk);
+    static const int tq = tuning_knob("QKV_BTILE", 0);   // tuning builds: 1 = split-bf16 on the 4-wave tile
+    if (w.prec == 1 && tq == 1) launch_qkv_t<QkvTileB, 1>(Wqkv, bqkv, wb, w, s, hk);
+    else if (w.prec == 1) launch_qkv_t<QkvTileW8, 1>(Wqkv, bqkv, wb, w, s, hk);
     else launch_qkv_t<QkvTileW8, 0>(Wqkv, bqkv, wb, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3(KVP / 64, w.nseg * H), dim3(1024), 0, s, w.kvpart,
                    w.kvfin, w.L);
@@ -689,11 +689,11 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
                 hipStream_t s, ProfileHook* hk) {
     // MLP0_TILE / MLP3_TILE / MLP0_BTILE select the alternative (equally correct) tile shapes in tuning builds; the ablation
     // variants (wrong results, timing only) exist only in a -DGATSSPG_PROFILING_BUILD library.
-    static const int t0 = tuning_knob("MLP0_TILE", 0), t3 = tuning_knob("MLP3_TILE", 0), tb0 = tuning_knob("MLP0_BTILE", 0);
+    static const int t0 = tuning_knob("MLP0_TILE", 0), t3 = tuning_knob("MLP3_TILE", 1), tb0 = tuning_knob("MLP0_BTILE", 0);
     (void)t0;
     if (w.prec == 1) {
         if (tb0 == 1) launch_mlp0_t<Mlp0TileB8, 0, 1>(W0, b0, wb, w, s, hk);
-        else launch_mlp0_t<Mlp0TileB, 0, 1>(W0, b0, wb, w, s, hk);
+        else launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, wb, w, s, hk);
     }
 #ifdef GATSSPG_PROFILING_BUILD
     else if (t0 == 11) launch_mlp0_t<Mlp0TileW8, 1, 0>(W0, b0, wb, w, s, hk);   // no global loads in the loop
@@ -703,7 +703,8 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
 #endif
     else launch_mlp0_t<Mlp0TileW8, 0, 0>(W0, b0, wb, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
-    if (w.prec == 1) launch_mlp3_t<Mlp3TileB, 0, 1>(W3, b3, wb, w, s, hk);
+    if (w.prec == 1 && t3 == 0) launch_mlp3_t<Mlp3Tile, 0, 1>(W3, b3, wb, w, s, hk);
+    else if (w.prec == 1) launch_mlp3_t<Mlp3TileTallW8, 0, 1>(W3, b3, wb, w, s, hk);
 #ifdef GATSSPG_PROFILING_BUILD
     else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3, 0>(W3, b3, wb, w, s, hk);   // steady-state loop cut: fixed cost only
 #endif
@@ -717,17 +718,19 @@ void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w
                    (smem_bytes<FinalTile>()), s, Wf, bf, w.Z, w.MD, w.MDT, w.L);
 }
 
-template <bool RAW>
+int score_tile_rows() { return ScoreTileW8::BM; }
+
+template <class T, bool RAW>
 static void launch_score_t(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk) {
-    using T = ScoreTileW8;
     allow_big_lds<score_exp_kernel<T, RAW>>();
-    GATSSPG_LAUNCH(hk, KID_SCORE_EXP, s, (score_exp_kernel<T, RAW>), dim3(xcd_grid(w.sc_nrt, w.sc_nct), w.L.b), dim3(T::THREADS),
+    const int nrt = (w.L.n1p + T::BM - 1) / T::BM;
+    GATSSPG_LAUNCH(hk, KID_SCORE_EXP, s, (score_exp_kernel<T, RAW>), dim3(xcd_grid(nrt, w.sc_nct), w.L.b), dim3(T::THREADS),
                    (smem_bytes<T>()), s, w.MDT, w.MD, conf, w.rowpart, w.colpart, w.L, scale);
 }
 
 void launch_score_exp(const Workspace& w, float* conf, float scale, int shifted, hipStream_t s, ProfileHook* hk) {
-    if (shifted) launch_score_t<true>(w, conf, scale, s, hk);
-    else launch_score_t<false>(w, conf, scale, s, hk);
+    if (shifted) launch_score_t<ScoreTileW8, true>(w, conf, scale, s, hk);
+    else launch_score_t<ScoreTileW8, false>(w, conf, scale, s, hk);
 }
 
 void launch_gats_wlt(const float* W, const float* P, const Workspace& w, int add_h, hipStream_t s, ProfileHook* hk) {

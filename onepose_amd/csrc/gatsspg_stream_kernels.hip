@@ -340,6 +340,7 @@ void launch_gats(const float* u1, const float* u2, const float* leaves, int num_
     if (num_leaf == 8) {
         const int nt = (w.L.n2 + 3) / 4;
         const int extra = h3 ? GATS_COPY_BLOCKS : 0;
+        // (capping the residency -- fewer, staggered rounds of workgroups -- was measured: no gain at 4-5 per CU, worse below)
         if (h3)
             GATSSPG_LAUNCH(hk, KID_GATS, s, gats_leaf8x4_kernel<true>, dim3(nt + extra, w.L.b), dim3(256), 0, s, u1, u2, leaves, w.Z,
                            dst, w.L, flags, raw_out, nt, h3, dq);
@@ -370,9 +371,11 @@ __device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int o
 //     CF_ROWS sums of nct partials; columns: this chunk's CF_COLS sums of nrt partials) -- no reduction launch.
 //   SHIFTED = true (1 / scale_factor > 80): the buffer holds S; conf = exp(S - colmax)/colsum * exp(S - rowmax)/rowsum
 //     with the maxima / sums precomputed by softmax_rowstat / softmax_colstat (the max-subtracting softmax, total range).
-// Each wave owns 4 whole rows of the strip (16 columns per lane and row, 16 x 16 B in flight per lane): the row arg-max
-// needs one butterfly per row and wave, the column arg-max is combined across the 4 waves through LDS.
-// VEC: n2 % 4 == 0 and conf 16-byte aligned -> a lane owns 4 x 4 consecutive columns; otherwise columns lane + 64 k.
+// Each wave owns 4 whole rows of the strip (CF_COLS / 64 columns per lane and row; the 4 x CF_NQ 16-byte loads of a lane
+// are issued first and fly while the normalisers are summed): the row arg-max needs one butterfly per row and wave, the
+// column arg-max is combined across the 4 waves through LDS.
+// VEC: n2 % 4 == 0 and conf 16-byte aligned -> a lane owns CF_NQ x 4 consecutive columns; otherwise columns lane + 64 k.
+constexpr int CF_NQ = CF_COLS / 256;
 template <bool VEC, bool SHIFTED>
 __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ conf, const float* __restrict__ rowpart,
                                                             const float* __restrict__ colpart, const float* __restrict__ rs_g,
@@ -393,6 +396,32 @@ __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ 
     const int nrows = min(CF_ROWS, L.n1 - i0);
     float* cf = conf + (size_t)f * L.n1 * L.n2;
 
+    // ---- this wave's 4 rows: every load of a lane is requested before anything else happens ----
+    auto lcol = [&](int q, int k) { return VEC ? 4 * lane + 256 * q + k : lane + 64 * (4 * q + k); };   // < CF_COLS
+    float e[4][CF_NQ][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = 4 * wave + u;
+        if (r < nrows) {   // wave-uniform
+            const size_t base = (size_t)(i0 + r) * L.n2;
+#pragma unroll
+            for (int q = 0; q < CF_NQ; ++q) {
+                if (VEC) {
+                    const int j = j0 + lcol(q, 0);
+                    if (j < L.n2) {
+                        const float4 x = *reinterpret_cast<const float4*>(cf + base + j);
+                        e[u][q][0] = x.x; e[u][q][1] = x.y; e[u][q][2] = x.z; e[u][q][3] = x.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int j = j0 + lcol(q, k);
+                        if (j < L.n2) e[u][q][k] = cf[base + j];
+                    }
+                }
+            }
+        }
+    }
     // ---- normalisers of this strip's rows and this chunk's columns ----
     if constexpr (!SHIFTED) {
         {
@@ -410,7 +439,7 @@ __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ 
         {
             const int jl = 4 * tid, j = j0 + jl;                    // 4 consecutive columns per thread
             float4 c = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (j < L.n2p) {                                        // n2p is a multiple of 128: all four in bounds
+            if (jl < CF_COLS && j < L.n2p) {                                        // n2p is a multiple of 128: all four in bounds
                 const float* src = colpart + (size_t)f * nrt * L.n2p + j;
                 const int per = (nrt + 15) / 16;
                 for (int r = 0; r < 16; ++r) {
@@ -424,59 +453,35 @@ __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ 
                     else { c.x += s.x; c.y += s.y; c.z += s.z; c.w += s.w; }
                 }
             }
-            *reinterpret_cast<float4*>(cs_s + jl) = c;
+            // the element loop multiplies by reciprocal normalisers: one IEEE division per column / row, not two per element
+            c.x = 1.f / c.x; c.y = 1.f / c.y; c.z = 1.f / c.z; c.w = 1.f / c.w;
+            if (jl < CF_COLS) *reinterpret_cast<float4*>(cs_s + jl) = c;
         }
         __syncthreads();
         if (tid < CF_ROWS) {
             float tot = red[0][tid];
 #pragma unroll
             for (int p = 1; p < 16; ++p) tot += red[p][tid];
-            rs_s[tid] = tot;
+            rs_s[tid] = 1.f / tot;
         }
     } else {
         for (int jl = tid; jl < CF_COLS; jl += 256) {
             const int j = j0 + jl;
-            cs_s[jl] = j < L.n2 ? cs_g[(size_t)f * L.n2p + j] : 1.f;
+            cs_s[jl] = j < L.n2 ? 1.f / cs_g[(size_t)f * L.n2p + j] : 1.f;
             csh_s[jl] = j < L.n2 ? cshift[(size_t)f * L.n2p + j] : 0.f;
         }
         if (tid < CF_ROWS) {
             const bool ok = tid < nrows;
-            rs_s[tid] = ok ? rs_g[(size_t)f * L.n1p + i0 + tid] : 1.f;
+            rs_s[tid] = ok ? 1.f / rs_g[(size_t)f * L.n1p + i0 + tid] : 1.f;
             rsh_s[tid] = ok ? rshift[(size_t)f * L.n1p + i0 + tid] : 0.f;
         }
     }
 
-    // ---- this wave's 4 rows: all 16 x 16 B of a lane are requested before any is used ----
-    auto lcol = [&](int q, int k) { return VEC ? 4 * lane + 256 * q + k : lane + 64 * (4 * q + k); };
-    float e[4][4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int r = 4 * wave + u;
-        if (r < nrows) {   // wave-uniform
-            const size_t base = (size_t)(i0 + r) * L.n2;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (VEC) {
-                    const int j = j0 + lcol(q, 0);
-                    if (j < L.n2) {
-                        const float4 x = *reinterpret_cast<const float4*>(cf + base + j);
-                        e[u][q][0] = x.x; e[u][q][1] = x.y; e[u][q][2] = x.z; e[u][q][3] = x.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int j = j0 + lcol(q, k);
-                        if (j < L.n2) e[u][q][k] = cf[base + j];
-                    }
-                }
-            }
-        }
-    }
     __syncthreads();   // normalisers visible
-    float csj[4][4], cshj[4][4], cmv[4][4];
-    int cmi[4][4];
+    float csj[CF_NQ][4], cshj[CF_NQ][4], cmv[CF_NQ][4];
+    int cmi[CF_NQ][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < CF_NQ; ++q)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             csj[q][k] = cs_s[lcol(q, k)];
@@ -495,17 +500,18 @@ __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ 
             float rv = -INFINITY;
             int ri = 0x7fffffff;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < CF_NQ; ++q) {
                 float c[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int j = j0 + lcol(q, k);
                     if (j < L.n2) {
                         const float x = e[u][q][k];
-                        if constexpr (SHIFTED) c[k] = (expf(x - cshj[q][k]) / csj[q][k]) * (expf(x - rshi) / rsi);
-                        else c[k] = (x / csj[q][k]) * (x / rsi);
+                        // csj / rsi hold RECIPROCAL sums: softmax(dim=1) * softmax(dim=2) = (E * 1/colsum) * (E * 1/rowsum)
+                        if constexpr (SHIFTED) c[k] = (expf(x - cshj[q][k]) * csj[q][k]) * (expf(x - rshi) * rsi);
+                        else c[k] = (x * csj[q][k]) * (x * rsi);
                         if (c[k] > cmv[q][k]) { cmv[q][k] = c[k]; cmi[q][k] = i; }
-                        if (c[k] > rv || (c[k] == rv && j < ri)) { rv = c[k]; ri = j; }
+                        if (c[k] > rv) { rv = c[k]; ri = j; }   // a lane visits its columns in increasing order: strict '>' keeps the first
                     }
                 }
                 if (VEC) {
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ 
     }
     // ---- column maxima of the strip: the 4 waves (ascending rows) are combined in order, strict '>' keeps the first row ----
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < CF_NQ; ++q)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             cmv_s[wave][lcol(q, k)] = cmv[q][k];
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ 
     __syncthreads();
     {
         const int jl = 4 * tid, j = j0 + jl;
-        if (j < L.n2p) {
+        if (jl < CF_COLS && j < L.n2p) {
             float4 v = *reinterpret_cast<const float4*>(&cmv_s[0][jl]);
             int4 a = *reinterpret_cast<const int4*>(&cmi_s[0][jl]);
 #pragma unroll
@@ -563,56 +569,100 @@ __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ 
 // mutual check, threshold, -1 fill (GATs_SuperGlue.py:220-237) straight from the finalize kernel's partials: the row
 // (max, arg-max) of query i is the first maximum over its nch chunk partials, the column arg-max of 3D point j the first
 // maximum over its nst strip partials (partials are ordered by increasing index; strict '>' keeps the first).
-//   row thread i:    j = argmax_j conf[i, :];  mutual0 = argmax_i conf[:, j] == i
-//   column thread j: i = argmax_i conf[:, j];  mutual1 = argmax_j conf[i, :] == j   (which implies mutual0 of i)
+//   row item i:    j = argmax_j conf[i, :];  mutual0 = argmax_i conf[:, j] == i
+//   column item j: i = argmax_i conf[:, j];  mutual1 = argmax_j conf[i, :] == j   (which implies mutual0 of i)
+// One workgroup = 32 items (rows, or columns) x 8 lanes per item: the strip reduction of a column is split 8 ways
+// (ranges in order, combined in order), so the dependent-load chains are nst / 8 long.
+constexpr int MT_ITEMS = 32;
+
 __global__ __launch_bounds__(256) void match_tail_kernel(const float* __restrict__ rmax_v, const int* __restrict__ rmax_i,
                                                          const float* __restrict__ cmax_v, const int* __restrict__ cmax_i,
                                                          float thr, int64_t* __restrict__ matches0,
                                                          int64_t* __restrict__ matches1, float* __restrict__ ms0,
                                                          float* __restrict__ ms1, ColLayout L, int nch, int nst) {
-    const int f = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float pv[8][MT_ITEMS];
+    __shared__ int pi[8][MT_ITEMS];
+    __shared__ float rowv[MT_ITEMS];
+    __shared__ int rowj[MT_ITEMS];
+    const int f = blockIdx.y, tid = threadIdx.x, it = tid & (MT_ITEMS - 1), grp = tid / MT_ITEMS;
+    const int nrb = L.n1p / MT_ITEMS;
+    const bool rows = (int)blockIdx.x < nrb;
+    const int base = (rows ? (int)blockIdx.x : (int)blockIdx.x - nrb) * MT_ITEMS;
     const float* rv = rmax_v + (size_t)f * nch * L.n1p;
     const int* ri = rmax_i + (size_t)f * nch * L.n1p;
     const float* cv = cmax_v + (size_t)f * nst * L.n2p;
     const int* ci = cmax_i + (size_t)f * nst * L.n2p;
-    auto rowarg = [&](int i, float& v) {
+    // first maximum over partials [tb, te) spaced `stride` apart, 8 loads in flight at a time
+    auto argpart = [&](const float* pvv, const int* pii, size_t stride, int tb, int te, float& v) {
         v = -INFINITY;
         int a = 0;
-        for (int c = 0; c < nch; ++c) {
-            const float x = rv[(size_t)c * L.n1p + i];
-            if (x > v) { v = x; a = ri[(size_t)c * L.n1p + i]; }
+        for (int t0 = tb; t0 < te; t0 += 8) {
+            float x[8];
+            int xi[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = t0 + u < te;
+                x[u] = in ? pvv[(size_t)(t0 + u) * stride] : -INFINITY;
+                xi[u] = in ? pii[(size_t)(t0 + u) * stride] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (x[u] > v) { v = x[u]; a = xi[u]; }
         }
         return a;
     };
-    auto colarg = [&](int j) {
-        float v = -INFINITY;
-        int a = 0;
-#pragma unroll 8
-        for (int t = 0; t < nst; ++t) {
-            const float x = cv[(size_t)t * L.n2p + j];
-            const int xi = ci[(size_t)t * L.n2p + j];
-            if (x > v) { v = x; a = xi; }
-        }
+    auto rowarg = [&](int i, float& v) { return argpart(rv + i, ri + i, (size_t)L.n1p, 0, nch, v); };
+    // first maximum of column j over this lane group's range of strips
+    auto colarg_part = [&](int j, float& v) {
+        const int per = (nst + 7) / 8;
+        const int tb = grp * per;
+        return argpart(cv + j, ci + j, (size_t)L.n2p, tb, min(nst, tb + per), v);
+    };
+    auto colarg_combine = [&]() {   // call with tid < MT_ITEMS after pv / pi are written and synchronised
+        float v = pv[0][it];
+        int a = pi[0][it];
+#pragma unroll
+        for (int g = 1; g < 8; ++g)
+            if (pv[g][it] > v) { v = pv[g][it]; a = pi[g][it]; }
         return a;
     };
-    if (idx < L.n1) {
+    if (rows) {
+        const int i = base + it;
+        const bool live = i < L.n1;
+        if (grp == 0) {
+            float v = 0.f;
+            const int j = live ? rowarg(i, v) : 0;
+            rowv[it] = v;
+            rowj[it] = j;
+        }
+        __syncthreads();
         float v;
-        const int j = rowarg(idx, v);
-        const bool mutual0 = colarg(j) == idx;
-        const float s0 = mutual0 ? v : 0.f;
-        const bool valid0 = mutual0 && s0 > thr;
-        matches0[(size_t)f * L.n1 + idx] = valid0 ? (int64_t)j : (int64_t)-1;
-        ms0[(size_t)f * L.n1 + idx] = s0;
-    } else if (idx >= L.n1p && idx - L.n1p < L.n2) {
-        const int j = idx - L.n1p;
-        const int i = colarg(j);
+        pi[grp][it] = colarg_part(rowj[it], v);
+        pv[grp][it] = v;
+        __syncthreads();
+        if (grp == 0 && live) {
+            const bool mutual0 = colarg_combine() == i;
+            const float s0 = mutual0 ? rowv[it] : 0.f;
+            const bool valid0 = mutual0 && s0 > thr;
+            matches0[(size_t)f * L.n1 + i] = valid0 ? (int64_t)rowj[it] : (int64_t)-1;
+            ms0[(size_t)f * L.n1 + i] = s0;
+        }
+    } else {
+        const int j = base + it;
+        const bool live = j < L.n2;
         float v;
-        const bool mutual1 = rowarg(i, v) == j;
-        const float s1 = mutual1 ? v : 0.f;
-        const bool valid1 = mutual1 && v > thr;
-        matches1[(size_t)f * L.n2 + j] = valid1 ? (int64_t)i : (int64_t)-1;
-        ms1[(size_t)f * L.n2 + j] = s1;
+        pi[grp][it] = colarg_part(live ? j : 0, v);
+        pv[grp][it] = v;
+        __syncthreads();
+        if (grp == 0 && live) {
+            const int i = colarg_combine();
+            float m;
+            const bool mutual1 = rowarg(i, m) == j;
+            const float s1 = mutual1 ? m : 0.f;
+            const bool valid1 = mutual1 && m > thr;
+            matches1[(size_t)f * L.n2 + j] = valid1 ? (int64_t)i : (int64_t)-1;
+            ms1[(size_t)f * L.n2 + j] = s1;
+        }
     }
 }
 
@@ -665,6 +715,7 @@ void launch_dual_softmax_match(const Workspace& w, float* conf, float scale, int
     const ColLayout& L = w.L;
     (void)scale;
     const dim3 gf(w.cf_nch, w.cf_nst, L.b);
+    const int nrt = (L.n1p + score_tile_rows() - 1) / score_tile_rows();
     const bool vec = (L.n2 & 3) == 0 && (reinterpret_cast<uintptr_t>(conf) & 15) == 0;
     if (shifted) {
         GATSSPG_LAUNCH(hk, KID_SOFTMAX_STATS, s, softmax_rowstat_kernel, dim3(L.n1, L.b), dim3(256), 0, s, conf, w.rshift, w.rs, L);
@@ -673,14 +724,14 @@ void launch_dual_softmax_match(const Workspace& w, float* conf, float scale, int
     }
 #define GATSSPG_FINALIZE(VEC_, SH_)                                                                                          \
     GATSSPG_LAUNCH(hk, KID_CONF_FINALIZE, s, (conf_finalize_kernel<VEC_, SH_>), gf, dim3(256), 0, s, conf, w.rowpart,         \
-                   w.colpart, w.rs, w.cs, w.rshift, w.cshift, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, L, w.sc_nct, w.sc_nrt,  \
+                   w.colpart, w.rs, w.cs, w.rshift, w.cshift, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, L, w.sc_nct, nrt,       \
                    w.cf_nch, w.cf_nst)
     if (vec && !shifted) GATSSPG_FINALIZE(true, false);
     else if (!shifted) GATSSPG_FINALIZE(false, false);
     else if (vec) GATSSPG_FINALIZE(true, true);
     else GATSSPG_FINALIZE(false, true);
 #undef GATSSPG_FINALIZE
-    const dim3 g1((L.n1p + L.n2p + 255) / 256, L.b);
+    const dim3 g1((L.n1p + L.n2p) / MT_ITEMS, L.b);
     GATSSPG_LAUNCH(hk, KID_MATCH_TAIL, s, match_tail_kernel, g1, dim3(256), 0, s, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, thr,
                    matches0, matches1, mscores0, mscores1, L, w.cf_nch, w.cf_nst);
 }
