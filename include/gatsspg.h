@@ -43,8 +43,10 @@ extern "C" {
  * the library never reads the environment:
  *   bit clear (default): exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's arithmetic (GATs_SuperGlue.py:191-193);
  *   GATSSPG_FLAG_PREC_BF16X3: split-bf16 -- every fp32 operand is a sum of two bf16 terms and each product three
- *     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE configs[2] "bf16 MFMA").  Measured against the fp32
- *     forward: conf within 1e-6, match indices identical (tests/test_hip_parity.py runs its golden cases under both).
+ *     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (BASELINE configs[2] "bf16 MFMA").  Measured against the reference
+ *     (tests/test_hip_parity.py runs every golden case under both modes): conf within 1e-6 abs of the fp32 forward; raw
+ *     arg-max indices identical except where the reference's own top-2 entries are closer than 1e-3 relative (1-2 of
+ *     64000 on the random-weight b=8 fixture, none on the others); thresholded matches identical on every fixture.
  * final_proj, the score contraction, GATs and all reductions are fp32 in both modes. */
 #define GATSSPG_FLAG_PREC_BF16X3 0x100
 /* layer kinds for gatsspg_attn_layer (GATs_SuperGlue.py:55-64) */

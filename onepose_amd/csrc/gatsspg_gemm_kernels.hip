@@ -19,6 +19,8 @@ using QkvTileW8 = GemmTile<128, QKV_BN, 4, 2, false>;     // both arithmetics: 8
 using QkvTileB = GemmTile<128, QKV_BN, 2, 2, false>;      // split-bf16 alternative (tuning builds): 4 waves, 64x32 per wave (31.2 vs 24.6 us)
 
 // PREC = 0: exact fp32 MFMA.  PREC = 1: split-bf16 main loop on the pre-split weight planes Whi / Wlo.
+// (forcing 80 VGPRs so that three 8-wave workgroups fit a CU -- the 756 tiles of the headline shape then fit 768 slots in one
+// round -- was measured: kernel -2 %, frames/s in flight unchanged; not kept)
 template <class T, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS) void qkv_kv_kernel(const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
                                                             const unsigned short* __restrict__ Whi,
@@ -141,44 +143,69 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
 //     KV / ksum come from the source segment: the same segment for 'self', the other side of the
 //     same frame for 'cross' (:57,62).
 // =====================================================================================================
-using ApplyTile = GemmTile<64, 64, 2, 2, false>;
+// One workgroup = one (64-column tile, head): K = 64 is two MFMA slabs, so there is nothing to pipeline -- KV_h, ksum_h and the
+// Q_h tile are fetched in one go into LDS (one barrier), z comes from the LDS copy of Q, four waves do one 32x32 tile each.
+constexpr int AP_AS = DH + 4;   // LDS row stride of KV_h [q][d]: b128 fragment reads conflict-free (17 * row mod 16 is a bijection)
 
 __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict__ kvfin, const float* __restrict__ Qbuf,
                                                          float* __restrict__ MSG, ColLayout L, int cross) {
-    using T = ApplyTile;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ float zs[64];
+    __shared__ __attribute__((aligned(16))) float KVs[DH * AP_AS];
+    __shared__ __attribute__((aligned(16))) float Qs[DH * 64];
+    __shared__ float ks[DH];
     __shared__ float zpart[4][64];
     const int ct = global_tile(L, blockIdx.x >> 2), h = blockIdx.x & 3;
-    const int c0 = ct * T::BN, ld = L.ld;
-    const TileSeg ts = tile_seg(L, c0, T::BN);
+    const int c0 = ct * 64, ld = L.ld;
+    const TileSeg ts = tile_seg(L, c0, 64);
     const int src = cross ? (ts.seg ^ 1) : ts.seg;
     const float* KV = kvfin + ((size_t)src * H + h) * KVP;  // [q][d]
-    const float* ksum = KV + DH * DH;
-    const float* Qh = Qbuf + (size_t)h * DH * ld;
-    const int tid = threadIdx.x;
+    const float* Qh = Qbuf + (size_t)h * DH * ld + c0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
-        const int col = tid & 63, part = tid >> 6;
+        vf4 kvr[4], qr[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = p * 256 + tid, row = idx >> 4, c4 = (idx & 15) * 4;
+            kvr[p] = ldg4(KV + row * DH + c4);
+            qr[p] = ldg4(Qh + (size_t)row * ld + c4);
+        }
+        if (tid < DH) ks[tid] = KV[DH * DH + tid];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = p * 256 + tid, row = idx >> 4, c4 = (idx & 15) * 4;
+            *reinterpret_cast<vf4*>(KVs + row * AP_AS + c4) = kvr[p];
+            *reinterpret_cast<vf4*>(Qs + row * 64 + c4) = qr[p];
+        }
+    }
+    __syncthreads();
+    {   // z denominators: 4 partial sums of 16 channels per column, combined in a fixed order below
+        const int col = lane, part = wave;
         float s = 0.f;
-#pragma unroll 4
-        for (int d = part * 16; d < part * 16 + 16; ++d) s += Qh[(size_t)d * ld + c0 + col] * ksum[d];
+#pragma unroll
+        for (int d = part * 16; d < part * 16 + 16; ++d) s += Qs[d * 64 + col] * ks[d];
         zpart[part][col] = s;
     }
-    f32x16 acc[T::TM][T::TN];
-    zero_acc(acc);
-    gemm_mainloop<T>(
-        acc, smem, DH / BK, [&](int kt) { return KV + kt * BK; }, DH,
-        [&](int kt) { return Qh + (size_t)kt * BK * ld + c0; }, ld);
-    if (tid < 64) zs[tid] = 1.f / (((zpart[0][tid] + zpart[1][tid]) + (zpart[2][tid] + zpart[3][tid])) + 1e-6f);
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {   // two 32-wide k slabs; lane half 0 takes k = s, half 1 takes k = 16 + s of each
+        const vf4* ap = reinterpret_cast<const vf4*>(KVs + (wm * 32 + l31) * AP_AS + kk * 32 + half * 16);
+        const float* bp = Qs + (kk * 32 + half * 16) * 64 + wn * 32 + l31;
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+            const vf4 a = ap[v4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bp[(v4 * 4 + e) * 64], acc, 0, 0, 0);
+        }
+    }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
     const int col = wn * 32 + l31;
-    const float z = zs[col];
+    const float z = 1.f / (((zpart[0][col] + zpart[1][col]) + (zpart[2][col] + zpart[3][col])) + 1e-6f);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int q = wm * 32 + mfma_row(r, half);
-        MSG[(size_t)(h * DH + q) * ld + c0 + col] = acc[0][0][r] * z;
+        MSG[(size_t)(h * DH + q) * ld + c0 + col] = acc[r] * z;
     }
 }
 
@@ -661,9 +688,7 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* w
 
 void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook* hk) {
     const int NT = active_tiles(w.L);
-    allow_big_lds<attn_apply_kernel>();
-    GATSSPG_LAUNCH(hk, KID_ATTN_APPLY, s, attn_apply_kernel, dim3(NT * H), dim3(256), (smem_bytes<ApplyTile>()), s, w.kvfin,
-                   w.Q, w.MSG, w.L, cross);
+    GATSSPG_LAUNCH(hk, KID_ATTN_APPLY, s, attn_apply_kernel, dim3(NT * H), dim3(256), 0, s, w.kvfin, w.Q, w.MSG, w.L, cross);
 }
 
 template <class T, int ABL, int PREC>

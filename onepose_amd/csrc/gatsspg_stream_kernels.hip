@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
                                                            const float* __restrict__ leaves, const float* Z, float* dst,
                                                            ColLayout L, int flags, int raw_out, int ntiles,
                                                            const float* __restrict__ h3, const float* __restrict__ dq) {
-    __shared__ float hs[D * 4];
+    __shared__ __attribute__((aligned(16))) float hs[D * 4];
+    __shared__ __attribute__((aligned(16))) float pre[D * 4];
     __shared__ float red3[4][4];
     __shared__ float redl[4][32];
     __shared__ float coef[4][9];
@@ -158,6 +159,15 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
         v[p] = valid ? *reinterpret_cast<const float4*>(Lf + (size_t)ch * lrow + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         u1r[p] = u1[ch];
     }
+#ifdef GATSSPG_PROFILING_BUILD
+    if (raw_out == 2) {   // read-only probe (profiling builds, wrong results): the leaf stream alone, one 4-byte store per thread
+        float acc = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc += (v[p].x + v[p].y) + (v[p].z + v[p].w);
+        if (acc == 1.2345e30f) dst[tid] = acc;
+        return;
+    }
+#endif
     {
         float4 a;
         if (FUSED_LOAD) {
@@ -173,33 +183,38 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
         } else {
             a = *reinterpret_cast<const float4*>(Z + (size_t)tid * L.ld + ycol);
         }
-        const float hv[4] = {a.x, a.y, a.z, a.w};
+        // s3[i] = sum over the 256 channels of h[ch][i] * u2[ch]: 4 values per lane are reduced over the 64 lanes with 7
+        // shuffles (two halving exchanges leave one value per lane -- point (lane & 1) * 2 + ((lane >> 1) & 1) -- then a
+        // 4-step butterfly), not 4 x 6
+        *reinterpret_cast<float4*>(hs + tid * 4) = a;
         const float u2v = u2[tid];
+        const float p0 = a.x * u2v, p1 = a.y * u2v, p2 = a.z * u2v, p3 = a.w * u2v;
+        const bool b0 = lane & 1, b1 = lane & 2;
+        float k0 = b0 ? p2 : p0, k1 = b0 ? p3 : p1;
+        k0 += __shfl_xor(b0 ? p0 : p2, 1);
+        k1 += __shfl_xor(b0 ? p1 : p3, 1);
+        float s = b1 ? k1 : k0;
+        s += __shfl_xor(b1 ? k0 : k1, 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            hs[tid * 4 + i] = hv[i];
-            float s = hv[i] * u2v;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) red3[w][i] = s;
-        }
+        for (int o = 4; o <= 32; o <<= 1) s += __shfl_xor(s, o);
+        if (lane < 4) red3[w][(lane & 1) * 2 + (lane >> 1)] = s;
     }
     {
+        // leaf logits: this lane's 4 leaves x its 8 channel rows, then over the 8 row lanes (lane bits 3..5) the same way:
+        // after two halving exchanges a lane holds leaf ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1) of its 16-byte piece
         float dl[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             dl[0] += v[p].x * u1r[p]; dl[1] += v[p].y * u1r[p]; dl[2] += v[p].z * u1r[p]; dl[3] += v[p].w * u1r[p];
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            dl[j] += __shfl_xor(dl[j], 8);
-            dl[j] += __shfl_xor(dl[j], 16);
-            dl[j] += __shfl_xor(dl[j], 32);
-        }
-        if (lane < 8) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) redl[w][c4 * 4 + j] = dl[j];
-        }
+        const bool b3 = lane & 8, b4 = lane & 16;
+        float k0 = b3 ? dl[2] : dl[0], k1 = b3 ? dl[3] : dl[1];
+        k0 += __shfl_xor(b3 ? dl[0] : dl[2], 8);
+        k1 += __shfl_xor(b3 ? dl[1] : dl[3], 8);
+        float s = b4 ? k1 : k0;
+        s += __shfl_xor(b4 ? k0 : k1, 16);
+        s += __shfl_xor(s, 32);
+        if (lane < 32) redl[w][c4 * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1)] = s;
     }
     __syncthreads();
     if (tid < 4) {
@@ -234,7 +249,9 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
         }
     }
     __syncthreads();
-    const float c0 = coef[pt][0];
+    // weighted sum of the leaves: the two 16-byte halves of a point meet in the even lane, which parks the row's value in
+    // LDS; the channel's thread then adds the h term, applies elu to its 4 points and stores 16 bytes (4 elu per thread
+    // instead of 8, no gather shuffles)
     const float cj0 = coef[pt][1 + lh * 4 + 0], cj1 = coef[pt][1 + lh * 4 + 1];
     const float cj2 = coef[pt][1 + lh * 4 + 2], cj3 = coef[pt][1 + lh * 4 + 3];
 #pragma unroll
@@ -242,19 +259,23 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
         const int ch = p * 32 + w * 8 + r;
         float part = ((cj0 * v[p].x + cj1 * v[p].y) + (cj2 * v[p].z + cj3 * v[p].w));
         part += __shfl_xor(part, 1);
-        float val = c0 * hs[ch * 4 + pt] + part;
-        if (!raw_out) val = elu_f(val);
-        // gather the 4 points of this channel row into the lane with c4 == 0 -> one 16-byte store
-        const float v1 = __shfl(val, (lane & ~7) | 2), v2 = __shfl(val, (lane & ~7) | 4), v3 = __shfl(val, (lane & ~7) | 6);
-        if (c4 == 0) {
-            float* o = dst + (size_t)ch * L.ld + ycol;
-            if (pv == 4) {
-                *reinterpret_cast<float4*>(o) = make_float4(val, v1, v2, v3);
-            } else {
-                o[0] = val;
-                if (pv > 1) o[1] = v1;
-                if (pv > 2) o[2] = v2;
-            }
+        if (lh == 0) pre[ch * 4 + pt] = part;
+    }
+    __syncthreads();
+    {
+        const float4 pr = *reinterpret_cast<const float4*>(pre + tid * 4);
+        const float4 h4 = *reinterpret_cast<const float4*>(hs + tid * 4);
+        float o0 = coef[0][0] * h4.x + pr.x, o1 = coef[1][0] * h4.y + pr.y, o2 = coef[2][0] * h4.z + pr.z, o3 = coef[3][0] * h4.w + pr.w;
+        if (!raw_out) {
+            o0 = elu_f(o0); o1 = elu_f(o1); o2 = elu_f(o2); o3 = elu_f(o3);
+        }
+        float* o = dst + (size_t)tid * L.ld + ycol;
+        if (pv == 4) {
+            *reinterpret_cast<float4*>(o) = make_float4(o0, o1, o2, o3);
+        } else {
+            o[0] = o0;
+            if (pv > 1) o[1] = o1;
+            if (pv > 2) o[2] = o2;
         }
     }
 }
@@ -336,7 +357,10 @@ bool gats_fuses_state_load(int num_leaf, int flags, const Workspace& w) {
 
 void launch_gats(const float* u1, const float* u2, const float* leaves, int num_leaf, int flags, float* dst,
                  const Workspace& w, hipStream_t s, ProfileHook* hk, const float* h3, const float* dq) {
-    const int raw_out = (flags & GATSSPG_FLAG_WITH_LINEAR_TRANSFORM) ? 1 : 0;
+    int raw_out = (flags & GATSSPG_FLAG_WITH_LINEAR_TRANSFORM) ? 1 : 0;
+#ifdef GATSSPG_PROFILING_BUILD
+    if (tuning_knob("GATS_PROBE", 0) && !h3) raw_out = 2;   // time the leaf stream alone
+#endif
     if (num_leaf == 8) {
         const int nt = (w.L.n2 + 3) / 4;
         const int extra = h3 ? GATS_COPY_BLOCKS : 0;

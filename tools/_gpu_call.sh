@@ -1,7 +1,3 @@
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2d; mkdir -p $O
-timeout 600 python -m pytest tests/test_hip_parity.py -m gpu -q --timeout=180 -p no:cacheprovider -x > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
-python tools/ab_tuning.py --kernel conf_finalize "" 2>&1 | tee $O/ab.log
-python tools/ab_tuning.py --kernel match_tail "" 2>&1 | tee -a $O/ab.log
-python tools/ab_tuning.py --kernel score_exp "" SCORE_TILE=1 2>&1 | tee -a $O/ab.log
-python tools/ab_tuning.py --kernel gats "" GATS_LDS_KB=36 GATS_LDS_KB=50 GATS_LDS_KB=28 2>&1 | tee -a $O/ab.log
+O=$R/gpurun_out/r2i; mkdir -p $O
+timeout 900 python -m pytest tests -m gpu -q --timeout=180 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log; grep -h "flips" $O/pytest.log | head
