@@ -1,3 +1,3 @@
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2i; mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -q --timeout=180 -p no:cacheprovider > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log; grep -h "flips" $O/pytest.log | head
+for s in 2 3 4 6; do python bench.py --streams $s --steps 120 --warmup 12 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('streams', $s, d['value'], d['config']['timed_pass_seconds'])"; done
