@@ -155,10 +155,11 @@ def pmc_traffic(kernel):
 
 
 def _timed_cpu(fn, max_seconds):
-    """Time fn() on the host: torch's intra-op thread count is chosen among {all cores, 32, 16} by one trial run each (the
-    small per-op GEMMs of these models regress when spread over >100 threads), then a bounded sample at the best setting."""
+    """Time fn() on the host: torch's intra-op thread count is chosen among {min(cores, 64), 32, 16} by one trial run each
+    (the small per-op GEMMs of these models regress when spread over >100 threads: 256 threads measured 3x slower than 16 on
+    the GPU box's host), then a bounded sample at the best setting.  host_cores is reported next to the threads used."""
     ncpu = os.cpu_count() or 1
-    cands = sorted({ncpu, min(ncpu, 32), min(ncpu, 16)}, reverse=True)
+    cands = sorted({min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True)
     prev = torch.get_num_threads()
     best, best_t = None, None
     try:
@@ -183,7 +184,7 @@ def _timed_cpu(fn, max_seconds):
     return dt, n, best
 
 
-def cpu_baseline(max_seconds=15.0):
+def cpu_baseline(max_seconds=10.0):
     """The reference algorithm on this host's cores, headline shape, batch 1: oracle/torch_oracle.py, i.e. the same stock
     PyTorch CPU ops (conv1d, einsum, InstanceNorm1d, softmax) the reference module executes -- the faster of the two oracle
     restatements (the literal numpy one, oracle/gatsspg_oracle.py, runs at about a quarter of this rate)."""

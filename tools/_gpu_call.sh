@@ -1,3 +1,3 @@
-for s in 2 3 4 6; do python bench.py --streams $s --steps 120 --warmup 12 --no-cpu-baseline 2>/dev/null | python -c "
+python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('streams', $s, d['value'], d['config']['timed_pass_seconds'])"; done
+d=json.loads(sys.stdin.read()); print(d['value'], d['config']['timed_pass_seconds'], d['config']['single_stream_frames_per_sec'], d['roofline']['frac'], d['cpu_baseline'])"
