@@ -108,14 +108,19 @@ __global__ __launch_bounds__(T::THREADS) void qkv_kv_kernel(const float* __restr
 }
 
 // K2  fixed-order sum of the KV partials of each (segment, head) -> KV[seg][h][q][d], ksum[seg][h][d].
-//     1024 threads = 64 elements x 16 tile-ranges: every range is summed in tile order by one wave
-//     (independent loads, one latency), the 16 range sums are combined in range order -> the result
-//     does not depend on scheduling.
+//     1024 threads = 64 float4 elements x 16 tile-ranges: every range is summed in tile order by one wave
+//     (8 independent 16-byte loads in flight at a time on clamped addresses -- a plain unrolled loop leaves a serial
+//     remainder loop, one load and one s_waitcnt vmcnt(0) per iteration), the 16 range sums are combined in range
+//     order -> the result does not depend on scheduling.  136 workgroups at the headline shape: one round (the
+//     one-float-per-thread form needed 520 workgroups of 16 waves on 512 slots -- 1.02 rounds).
+constexpr int KVP4 = KVP / 4;
+static_assert(KVP % 4 == 0, "KV partials are summed as float4");
+
 __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict__ kvpart, float* __restrict__ kvfin,
                                                         ColLayout L) {
-    __shared__ float red[16][64];
+    __shared__ float4 red[16][64];
     const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + el;
+    const int e4 = min((int)blockIdx.x * 64 + el, KVP4 - 1);   // clamped: the last block's spare lanes redo element KVP4 - 1
     const int seg = blockIdx.y / H, h = blockIdx.y % H;
     const int frame = seg >> 1, side = seg & 1;
     if (!((L.side_mask >> side) & 1)) return;
@@ -123,16 +128,26 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
     const int nt = (side ? L.n2p : L.n1p) / QKV_BN;
     const int per = (nt + 15) / 16;
     const int tb = part * per, te = min(nt, tb + per);
-    float s = 0.f;
-#pragma unroll 8
-    for (int t = tb; t < te; ++t) s += kvpart[((size_t)(t0 + t) * H + h) * KVP + e];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int tt = tb; tt < te; tt += 8) {
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            x[u] = *reinterpret_cast<const float4*>(kvpart + ((size_t)(t0 + min(tt + u, nt - 1)) * H + h) * KVP + 4 * e4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (tt + u < te) { s.x += x[u].x; s.y += x[u].y; s.z += x[u].z; s.w += x[u].w; }
+    }
     red[part][el] = s;
     __syncthreads();
-    if (part == 0) {
-        float tot = red[0][el];
+    if (part == 0 && (int)blockIdx.x * 64 + el < KVP4) {
+        float4 tot = red[0][el];
 #pragma unroll
-        for (int p = 1; p < 16; ++p) tot += red[p][el];
-        kvfin[((size_t)seg * H + h) * KVP + e] = tot;
+        for (int p = 1; p < 16; ++p) {
+            const float4 r = red[p][el];
+            tot.x += r.x; tot.y += r.y; tot.z += r.z; tot.w += r.w;
+        }
+        *reinterpret_cast<float4*>(kvfin + ((size_t)seg * H + h) * KVP + 4 * e4) = tot;
     }
 }
 
@@ -342,15 +357,24 @@ __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restric
     const int per = (nt + 15) / 16;
     const int tb = part * per, te = min(nt, tb + per);
     double S = 0.0, QP = 0.0;
-#pragma unroll 8
-    for (int t = tb; t < te; ++t) {
-        const double st = (double)statpart[((size_t)(t0 + t) * 2 + 0) * 512 + row];
-        const double mt = (double)statpart[((size_t)(t0 + t) * 2 + 1) * 512 + row];
-        const int nv = min(MLP0_BN, n - t * MLP0_BN);   // real columns of tile t of this segment (<= 0: pad-only tile)
-        if (nv > 0) {
-            const double inv = nv == MLP0_BN ? 1.0 / MLP0_BN : 1.0 / nv;
-            S += st;
-            QP += mt + st * st * inv;
+    for (int tt = tb; tt < te; tt += 8) {   // 2 x 8 loads in flight at a time on clamped addresses (see kv_final_kernel)
+        float xs[8], xm[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t tile = (size_t)(t0 + min(tt + u, nt - 1));
+            xs[u] = statpart[(tile * 2 + 0) * 512 + row];
+            xm[u] = statpart[(tile * 2 + 1) * 512 + row];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = tt + u;
+            const int nv = min(MLP0_BN, n - t * MLP0_BN);   // real columns of tile t of this segment (<= 0: pad-only tile)
+            if (t < te && nv > 0) {
+                const double st = (double)xs[u], mt = (double)xm[u];
+                const double inv = nv == MLP0_BN ? 1.0 / MLP0_BN : 1.0 / nv;
+                S += st;
+                QP += mt + st * st * inv;
+            }
         }
     }
     red[0][part][rl] = S;
@@ -682,7 +706,7 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* w
     if (w.prec == 1 && tq == 1) launch_qkv_t<QkvTileB, 1>(Wqkv, bqkv, wb, w, s, hk);
     else if (w.prec == 1) launch_qkv_t<QkvTileW8, 1>(Wqkv, bqkv, wb, w, s, hk);
     else launch_qkv_t<QkvTileW8, 0>(Wqkv, bqkv, wb, w, s, hk);
-    GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3(KVP / 64, w.nseg * H), dim3(1024), 0, s, w.kvpart,
+    GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3((KVP4 + 63) / 64, w.nseg * H), dim3(1024), 0, s, w.kvpart,
                    w.kvfin, w.L);
 }
 

@@ -151,12 +151,33 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
     const int pt = c4 >> 1, lh = c4 & 1;
     const bool valid = pt < pv;
 
+    // the 3D-point descriptors are requested FIRST: loads retire in order, so the h-only work below (s3, the LDS copy of h)
+    // waits for one load instead of for the whole leaf tile and runs while the leaves stream in
+    float4 a;
+    if (FUSED_LOAD) {
+        const float* hp = h3 + ((size_t)f * D + tid) * L.n2 + n0;
+        if (pv == 4 && (L.n2 & 3) == 0) {
+            a = *reinterpret_cast<const float4*>(hp);
+        } else {
+            a.x = hp[0];
+            a.y = pv > 1 ? hp[1] : 0.f;
+            a.z = pv > 2 ? hp[2] : 0.f;
+            a.w = pv > 3 ? hp[3] : 0.f;
+        }
+    } else {
+        a = *reinterpret_cast<const float4*>(Z + (size_t)tid * L.ld + ycol);
+    }
+    const float u2v = u2[tid];
+    // UNCONDITIONAL loads: lanes of points beyond n2 (last tile only) re-read point 0 of the tile -- finite values whose
+    // results are never stored.  (A `valid ? load : 0` form compiles to exec-masked branches with an s_waitcnt vmcnt(0)
+    // in the middle of the sequence: the 8 loads of a lane were in flight 3 + 5 instead of 8 at a time.)
+    const int c4l = valid ? c4 : (c4 & 1);
     float4 v[8];
     float u1r[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int ch = p * 32 + w * 8 + r;
-        v[p] = valid ? *reinterpret_cast<const float4*>(Lf + (size_t)ch * lrow + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[p] = *reinterpret_cast<const float4*>(Lf + (size_t)ch * lrow + 4 * c4l);
         u1r[p] = u1[ch];
     }
 #ifdef GATSSPG_PROFILING_BUILD
@@ -169,25 +190,10 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
     }
 #endif
     {
-        float4 a;
-        if (FUSED_LOAD) {
-            const float* hp = h3 + ((size_t)f * D + tid) * L.n2 + n0;
-            if (pv == 4 && (L.n2 & 3) == 0) {
-                a = *reinterpret_cast<const float4*>(hp);
-            } else {
-                a.x = hp[0];
-                a.y = pv > 1 ? hp[1] : 0.f;
-                a.z = pv > 2 ? hp[2] : 0.f;
-                a.w = pv > 3 ? hp[3] : 0.f;
-            }
-        } else {
-            a = *reinterpret_cast<const float4*>(Z + (size_t)tid * L.ld + ycol);
-        }
         // s3[i] = sum over the 256 channels of h[ch][i] * u2[ch]: 4 values per lane are reduced over the 64 lanes with 7
         // shuffles (two halving exchanges leave one value per lane -- point (lane & 1) * 2 + ((lane >> 1) & 1) -- then a
         // 4-step butterfly), not 4 x 6
         *reinterpret_cast<float4*>(hs + tid * 4) = a;
-        const float u2v = u2[tid];
         const float p0 = a.x * u2v, p1 = a.y * u2v, p2 = a.z * u2v, p3 = a.w * u2v;
         const bool b0 = lane & 1, b1 = lane & 2;
         float k0 = b0 ? p2 : p0, k1 = b0 ? p3 : p1;
@@ -400,7 +406,10 @@ __device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int o
 // column arg-max is combined across the 4 waves through LDS.
 // VEC: n2 % 4 == 0 and conf 16-byte aligned -> a lane owns CF_NQ x 4 consecutive columns; otherwise columns lane + 64 k.
 constexpr int CF_NQ = CF_COLS / 256;
-template <bool VEC, bool SHIFTED>
+// SMALL: at most 8 row partials per range (nct <= 128, i.e. n2 <= 8192) and one column partial per range (nrt <= 16, n1 <=
+// 2048): the prologue is then straight-line code whose loads are all issued up front.  Larger problems take the looped
+// prologue (hipcc drains every outstanding load -- the rows too -- in front of a loop that contains loads).
+template <bool VEC, bool SHIFTED, bool SMALL>
 __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ conf, const float* __restrict__ rowpart,
                                                             const float* __restrict__ colpart, const float* __restrict__ rs_g,
                                                             const float* __restrict__ cs_g, const float* __restrict__ rshift,
@@ -420,66 +429,90 @@ __global__ __launch_bounds__(256) void conf_finalize_kernel(float* __restrict__ 
     const int nrows = min(CF_ROWS, L.n1 - i0);
     float* cf = conf + (size_t)f * L.n1 * L.n2;
 
-    // ---- this wave's 4 rows: every load of a lane is requested before anything else happens ----
+    // Load order = wait order (loads retire in order): first the partials of the normalisers into registers, then this wave's
+    // 4 rows (every 16-byte load of a lane), then the sums -- they wait for the partials only, the rows keep streaming.
     auto lcol = [&](int q, int k) { return VEC ? 4 * lane + 256 * q + k : lane + 64 * (4 * q + k); };   // < CF_COLS
+    const int pr_r = tid & (CF_ROWS - 1), pr_g = tid / CF_ROWS;   // row partials: 16 rows x 16 ranges of the nct partials
+    const int pr_per = (nct + 15) / 16;
+    const int pr_tb = pr_g * pr_per, pr_te = min(nct, pr_tb + pr_per);
+    const float* pr_src = rowpart + (size_t)f * nct * L.n1p + i0 + pr_r;
+    const int pc_jl = 4 * tid, pc_j = j0 + pc_jl;                  // column partials: 4 consecutive columns per thread
+    const bool pc_on = pc_jl < CF_COLS && pc_j < L.n2p;            // n2p is a multiple of 128: all four in bounds
+    const float* pc_src = colpart + (size_t)f * nrt * L.n2p + pc_j;
+    const int pc_per = (nrt + 15) / 16;
+    float xr[8];
+    float4 xc[16];
+    if constexpr (!SHIFTED && SMALL) {
+        // every load below is UNCONDITIONAL on a clamped (always valid) address; out-of-range values are discarded afterwards.
+        // (Guarded loads compile to exec-masked branches, and the waits hipcc places around those are vmcnt(0): the rows then
+        // cannot stream under the sums.)
+        const float* pr_row = rowpart + (size_t)f * nct * L.n1p + i0 + min(pr_r, nrows - 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xr[u] = pr_row[(size_t)min(pr_tb + u, nct - 1) * L.n1p];
+        const float* pc_col = colpart + (size_t)f * nrt * L.n2p + min(pc_j, L.n2p - 4);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) xc[t] = *reinterpret_cast<const float4*>(pc_col + (size_t)min(t, nrt - 1) * L.n2p);
+    }
     float e[4][CF_NQ][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int r = 4 * wave + u;
-        if (r < nrows) {   // wave-uniform
-            const size_t base = (size_t)(i0 + r) * L.n2;
+        const size_t base = (size_t)(i0 + min(4 * wave + u, nrows - 1)) * L.n2;
 #pragma unroll
-            for (int q = 0; q < CF_NQ; ++q) {
-                if (VEC) {
-                    const int j = j0 + lcol(q, 0);
-                    if (j < L.n2) {
-                        const float4 x = *reinterpret_cast<const float4*>(cf + base + j);
-                        e[u][q][0] = x.x; e[u][q][1] = x.y; e[u][q][2] = x.z; e[u][q][3] = x.w;
-                    }
-                } else {
+        for (int q = 0; q < CF_NQ; ++q) {
+            if (VEC) {
+                const float4 x = *reinterpret_cast<const float4*>(cf + base + min(j0 + lcol(q, 0), L.n2 - 4));
+                e[u][q][0] = x.x; e[u][q][1] = x.y; e[u][q][2] = x.z; e[u][q][3] = x.w;
+            } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int j = j0 + lcol(q, k);
-                        if (j < L.n2) e[u][q][k] = cf[base + j];
-                    }
-                }
+                for (int k = 0; k < 4; ++k) e[u][q][k] = cf[base + min(j0 + lcol(q, k), L.n2 - 1)];
             }
         }
     }
-    // ---- normalisers of this strip's rows and this chunk's columns ----
+    // ---- normalisers of this strip's rows and this chunk's columns (fixed order: 16 ranges summed in order, combined in order) ----
     if constexpr (!SHIFTED) {
         {
-            const int r = tid & (CF_ROWS - 1), g = tid / CF_ROWS;   // 16 rows x 16 partial ranges
-            const int per = (nct + 15) / 16;
-            const int tb = g * per, te = min(nct, tb + per);
             float s = 0.f;
-            if (r < nrows) {
-                const float* src = rowpart + (size_t)f * nct * L.n1p + i0 + r;
-#pragma unroll 4
-                for (int t = tb; t < te; ++t) s += src[(size_t)t * L.n1p];
+            if constexpr (SMALL) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += (pr_r < nrows && pr_tb + u < pr_te) ? xr[u] : 0.f;
+            } else if (pr_r < nrows) {
+                for (int t0 = pr_tb; t0 < pr_te; t0 += 8) {   // 8 loads in flight at a time, summed in order
+                    float x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = t0 + u < pr_te ? pr_src[(size_t)(t0 + u) * L.n1p] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (t0 + u < pr_te) s += x[u];
+                }
             }
-            red[g][r] = s;
+            red[pr_g][pr_r] = s;
         }
         {
-            const int jl = 4 * tid, j = j0 + jl;                    // 4 consecutive columns per thread
             float4 c = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (jl < CF_COLS && j < L.n2p) {                                        // n2p is a multiple of 128: all four in bounds
-                const float* src = colpart + (size_t)f * nrt * L.n2p + j;
-                const int per = (nrt + 15) / 16;
-                for (int r = 0; r < 16; ++r) {
-                    const int tb = r * per, te = min(nrt, tb + per);
-                    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int t = tb; t < te; ++t) {
-                        const float4 x = *reinterpret_cast<const float4*>(src + (size_t)t * L.n2p);
-                        s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+            if constexpr (SMALL) {   // one partial per range -> a plain in-order sum
+                if (pc_on) {
+                    c = xc[0];
+#pragma unroll
+                    for (int t = 1; t < 16; ++t)
+                        if (t < nrt) { c.x += xc[t].x; c.y += xc[t].y; c.z += xc[t].z; c.w += xc[t].w; }
+                }
+            } else if (pc_on) {
+                {
+                    for (int r = 0; r < 16; ++r) {
+                        const int tb = r * pc_per, te = min(nrt, tb + pc_per);
+                        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int t = tb; t < te; ++t) {
+                            const float4 x = *reinterpret_cast<const float4*>(pc_src + (size_t)t * L.n2p);
+                            s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+                        }
+                        if (r == 0) c = s;
+                        else { c.x += s.x; c.y += s.y; c.z += s.z; c.w += s.w; }
                     }
-                    if (r == 0) c = s;
-                    else { c.x += s.x; c.y += s.y; c.z += s.z; c.w += s.w; }
                 }
             }
             // the element loop multiplies by reciprocal normalisers: one IEEE division per column / row, not two per element
             c.x = 1.f / c.x; c.y = 1.f / c.y; c.z = 1.f / c.z; c.w = 1.f / c.w;
-            if (jl < CF_COLS) *reinterpret_cast<float4*>(cs_s + jl) = c;
+            if (pc_jl < CF_COLS) *reinterpret_cast<float4*>(cs_s + pc_jl) = c;
         }
         __syncthreads();
         if (tid < CF_ROWS) {
@@ -746,14 +779,17 @@ void launch_dual_softmax_match(const Workspace& w, float* conf, float scale, int
         GATSSPG_LAUNCH(hk, KID_SOFTMAX_STATS, s, softmax_colstat_kernel, dim3((L.n2 + 255) / 256, L.b), dim3(256), 0, s, conf,
                        w.cshift, w.cs, L);
     }
-#define GATSSPG_FINALIZE(VEC_, SH_)                                                                                          \
-    GATSSPG_LAUNCH(hk, KID_CONF_FINALIZE, s, (conf_finalize_kernel<VEC_, SH_>), gf, dim3(256), 0, s, conf, w.rowpart,         \
+    const bool small = w.sc_nct <= 128 && nrt <= 16;
+#define GATSSPG_FINALIZE(VEC_, SH_, SM_)                                                                                     \
+    GATSSPG_LAUNCH(hk, KID_CONF_FINALIZE, s, (conf_finalize_kernel<VEC_, SH_, SM_>), gf, dim3(256), 0, s, conf, w.rowpart,    \
                    w.colpart, w.rs, w.cs, w.rshift, w.cshift, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, L, w.sc_nct, nrt,       \
                    w.cf_nch, w.cf_nst)
-    if (vec && !shifted) GATSSPG_FINALIZE(true, false);
-    else if (!shifted) GATSSPG_FINALIZE(false, false);
-    else if (vec) GATSSPG_FINALIZE(true, true);
-    else GATSSPG_FINALIZE(false, true);
+    if (vec && !shifted && small) GATSSPG_FINALIZE(true, false, true);
+    else if (vec && !shifted) GATSSPG_FINALIZE(true, false, false);
+    else if (!shifted && small) GATSSPG_FINALIZE(false, false, true);
+    else if (!shifted) GATSSPG_FINALIZE(false, false, false);
+    else if (vec) GATSSPG_FINALIZE(true, true, true);
+    else GATSSPG_FINALIZE(false, true, true);
 #undef GATSSPG_FINALIZE
     const dim3 g1((L.n1p + L.n2p) / MT_ITEMS, L.b);
     GATSSPG_LAUNCH(hk, KID_MATCH_TAIL, s, match_tail_kernel, g1, dim3(256), 0, s, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, thr,
