@@ -34,6 +34,18 @@ __global__ __launch_bounds__(T::THREADS) void qkv_kv_kernel(const float* __restr
     const int c0 = ct * T::BN;
     const int ld = L.ld;
     const float* A = Wqkv + (size_t)rt * 128 * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    // this lane's 16 bias values per MFMA tile (rows 8k + 4 half + 0..3 of the tile: four 16-byte loads), requested BEFORE the
+    // main loop.  (Read in the epilogue next to elu's branch they became 16 dependent load -> wait -> write rounds per lane.)
+    float bias[T::TM][16];
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const vf4 b4 = ldg4(bqkv + rt * 128 + (wm * T::TM + tm) * 32 + 8 * k + 4 * half);
+            bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
+        }
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     if constexpr (PREC == 1) {
@@ -48,11 +60,12 @@ __global__ __launch_bounds__(T::THREADS) void qkv_kv_kernel(const float* __restr
             [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
     }
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
     if (rt < 2) {
-        const float* bq = bqkv + rt * 128;
-        store_tile_via_lds<T>(acc, smem, Qbuf + (size_t)rt * 128 * ld + c0, ld, [&](int row, float v) { return elu1(v + bq[row]) + 1.f; });
+#pragma unroll
+        for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][0][r] = elu1_select(acc[tm][0][r] + bias[tm][r]) + 1.f;
+        store_tile_via_lds<T>(acc, smem, Qbuf + (size_t)rt * 128 * ld + c0, ld, [](int, float v) { return v; });
         return;
     }
     // ---- K_h / V_h tile -> LDS -> KV partial ----
@@ -66,9 +79,10 @@ __global__ __launch_bounds__(T::THREADS) void qkv_kv_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) {
             const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);  // 0..63 = K_h channel d, 64..127 = V_h channel q
             const int col = wn * 32 + l31;
-            float v = acc[tm][0][r] + bqkv[256 + h * 128 + row];
-            if (row < 64) v = elu1(v) + 1.f;
-            if (col >= ts.valid) v = 0.f;  // pad columns must not enter the sums (elu(0)+1 = 1)
+            float v = acc[tm][0][r] + bias[tm][r];
+            const float kf = elu1_select(v) + 1.f;
+            v = row < 64 ? kf : v;
+            v = col >= ts.valid ? 0.f : v;  // pad columns must not enter the sums (elu(0)+1 = 1)
             Tl[row * TS + col] = v;
         }
     __syncthreads();
@@ -259,6 +273,16 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
     ct = global_tile(L, ct * TPW) / TPW;   // windows and segments are multiples of 128 columns
     const int c0 = ct * T::BN, ld = L.ld;
     const float* A = W0 + (size_t)rt * T::BM * 512;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    float bias[T::TM][16];   // requested before the main loop (see qkv_kv_kernel)
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const vf4 b4 = ldg4(b0 + rt * T::BM + (wm * T::TM + tm) * 32 + 8 * k + 4 * half);
+            bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
+        }
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     // ABL == 5 (profiling): every workgroup streams the SAME weight panel and the SAME column tile (cache-hot operands)
@@ -275,8 +299,6 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
     } else {
         gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL)>(acc, smem, 512 / BK, al, 512, bl, ld);
     }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
     const unsigned long long t_loop = trace ? wall_clock64() : 0;
     const TileSeg ts = tile_seg(L, c0, T::BN);
     constexpr int TS = T::BN + 1;
@@ -289,10 +311,11 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
             for (int r = 0; r < 16; ++r) {
                 const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);
                 const int col = (wn * T::TN + tn) * 32 + l31;
-                Tl[row * TS + col] = acc[tm][tn][r] + b0[rt * T::BM + row];
+                Tl[row * TS + col] = acc[tm][tn][r] + bias[tm][r];
             }
     __syncthreads();
     // the tile leaves through LDS as 16-byte stores: 16 lanes cover one 256-byte row segment
+#pragma unroll
     for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
         const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
         const float* t = Tl + row * TS + c4;
@@ -312,9 +335,10 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
         const float pivot = Tl[row * TS + sub * MLP0_BN];
         const float* tr = Tl + row * TS + sub * MLP0_BN + part * CPL;
         float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
+#pragma unroll
         for (int m = 0; m < CPL; ++m) {
-            const float d = (part * CPL + m < valid) ? tr[m] - pivot : 0.f;
+            const float t = tr[m];                                           // unconditional LDS read (a guarded one becomes a
+            const float d = (part * CPL + m < valid) ? t - pivot : 0.f;      // branch + s_waitcnt per element), masked afterwards
             s1 += d;
             s2 += d * d;
         }

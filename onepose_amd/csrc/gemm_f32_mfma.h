@@ -504,7 +504,8 @@ __device__ __forceinline__ void store_tile_via_lds(const f32x16 (&acc)[T::TM][T:
                 smem[row * TS + (wn * T::TN + tn) * 32 + l31] = f(row, acc[tm][tn][r]);
             }
     __syncthreads();
-    for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
+#pragma unroll
+    for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {   // compile-time trip count: all LDS reads first, then the stores
         const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
         *reinterpret_cast<vf4*>(dst + (size_t)row * ld + c4) = *reinterpret_cast<const vf4*>(smem + row * TS + c4);
     }
@@ -534,5 +535,11 @@ __device__ __forceinline__ bool xcd_tile_map(int MT, int NT, int& rt, int& ct) {
 inline int xcd_grid(int MT, int NT) { return 8 * MT * ((NT + 7) / 8); }
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// same values, branch-free: both sides are evaluated and selected (epilogues that apply elu to 16-32 accumulator values per
+// lane: a divergent branch per value serialises whatever sits next to it)
+__device__ __forceinline__ float elu1_select(float x) {
+    const float e = expm1f(fminf(x, 0.f));
+    return x > 0.f ? x : e;
+}
 
 }  // namespace gatsspg
