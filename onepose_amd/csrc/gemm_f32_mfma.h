@@ -272,9 +272,11 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     float* buf0 = smem;
     float* buf1 = smem + T::STAGE_FLOATS;
     const int last = KT - 1;
-    gload(0, ra0, rb0, rx0);
-    swrite(buf0, ra0, rb0, rx0);
+    // slab 0 goes through set 1 so that slab 1 (set 0) is requested in the same breath: the LDS write of slab 0 waits for the
+    // first group only (loads retire in order), and step 0 no longer stalls a full round trip on slab 1
+    gload(0, ra1, rb1, rx1);
     gload(min(1, last), ra0, rb0, rx0);   // set 0 <- slab 1
+    swrite(buf0, ra1, rb1, rx1);
     gload(min(2, last), ra1, rb1, rx1);   // set 1 <- slab 2
     __syncthreads();
     // step i (even): compute buf0; write slab i+1 (set 0) -> buf1; then reload set 0 <- slab i+3
@@ -443,9 +445,9 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
     unsigned short* buf0 = smem;
     unsigned short* buf1 = smem + LY::STAGE;
     const int last = KT - 1;
-    gload(0, ra0, rb0, rx0);
-    swrite(buf0, ra0, rb0, rx0);
+    gload(0, ra1, rb1, rx1);              // slab 0 through set 1, slab 1 (set 0) requested together with it (see gemm_mainloop_ex)
     gload(min(1, last), ra0, rb0, rx0);
+    swrite(buf0, ra1, rb1, rx1);
     gload(min(2, last), ra1, rb1, rx1);
     __syncthreads();
     // step i: MFMAs of slab i, slab i+1 (in registers since step i-2) is split and written to the free buffer, the freed
