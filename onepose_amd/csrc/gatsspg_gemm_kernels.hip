@@ -549,7 +549,10 @@ __global__ __launch_bounds__(256) void final_proj_norm_kernel(const float* __res
 //     RAW (1 / scale_factor > 80): the scaled scores themselves are written, no sums (max-subtracting path).
 //     A = point-major query descriptors MDT (row-major [n][256]), B = channel-major 3D descriptors MD.
 // =====================================================================================================
-using ScoreTileW8 = GemmTile<SC_BM, SC_BN, 4, 2, false>;    // 128x64 on 8 waves (a 256x64 tile -- one round of workgroups instead of 1.7 -- measured slower: 52.7 vs 46.4 us)
+using ScoreTileW8 = GemmTile<SC_BM, SC_BN, 4, 2, false>;        // default: 128x64 on 8 waves: 880 tiles at 1000/7000 = 1.7 rounds of the 512 slots
+using ScoreTileSq = GemmTile<SC_BM, 2 * SC_BN, 2, 4, false>;    // alternative (tuning builds): 128x128 on 8 waves, 440 tiles = one round
+// Both one-round shapes measured SLOWER than 1.7 rounds of 128x64: 128x128 48.4 vs 45.3 us (event-timed), 256x64 (90 KB of LDS,
+// one workgroup per CU) 52.7 vs 46.4 us; three 128x64 workgroups per CU (80 VGPRs) unchanged.
 
 template <class T, bool RAW>
 __global__ __launch_bounds__(T::THREADS) void score_exp_kernel(const float* __restrict__ MDT, const float* __restrict__ MD,
@@ -615,18 +618,18 @@ __global__ __launch_bounds__(T::THREADS) void score_exp_kernel(const float* __re
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
         if (hp == 0 && rt * T::BM + row < L.n1p) rowpart[((size_t)frame * nct + ct) * L.n1p + rt * T::BM + row] = s;
-        constexpr int NQ = T::THREADS / 64, RPQ = T::BM / NQ;
-        const int c = tid & 63, qp = tid >> 6;
+        constexpr int NQ = T::THREADS / T::BN, RPQ = T::BM / NQ;   // NQ row groups of RPQ rows, one thread per (group, column)
+        const int c = tid % T::BN, qp = tid / T::BN;
         float t = 0.f;
 #pragma unroll 8
         for (int m = 0; m < RPQ; ++m) t += Tl[(qp * RPQ + m) * TS + c];
         __syncthreads();
-        Tl[qp * 64 + c] = t;   // re-use the tile head for the NQ x 64 part sums
+        Tl[qp * T::BN + c] = t;   // re-use the tile head for the NQ x BN part sums
         __syncthreads();
-        if (tid < 64) {
+        if (tid < T::BN) {
             float tot = 0.f;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) tot += Tl[q * 64 + tid];
+            for (int q = 0; q < NQ; ++q) tot += Tl[q * T::BN + tid];
             colpart[((size_t)frame * nrt + rt) * L.n2p + ct * T::BN + tid] = tot;
         }
     }
@@ -791,18 +794,26 @@ void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w
                    (smem_bytes<FinalTile>()), s, Wf, bf, w.Z, w.MD, w.MDT, w.L);
 }
 
-int score_tile_rows() { return ScoreTileW8::BM; }
+static bool score_square() {
+    static const int t = tuning_knob("SCORE_TILE", 0);   // 0 (default): 128x64; 1 (tuning builds): 128x128
+    return t == 1;
+}
+int score_tile_rows() { return SC_BM; }
+int score_tile_cols() { return score_square() ? ScoreTileSq::BN : ScoreTileW8::BN; }
 
 template <class T, bool RAW>
 static void launch_score_t(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk) {
     allow_big_lds<score_exp_kernel<T, RAW>>();
     const int nrt = (w.L.n1p + T::BM - 1) / T::BM;
-    GATSSPG_LAUNCH(hk, KID_SCORE_EXP, s, (score_exp_kernel<T, RAW>), dim3(xcd_grid(nrt, w.sc_nct), w.L.b), dim3(T::THREADS),
+    GATSSPG_LAUNCH(hk, KID_SCORE_EXP, s, (score_exp_kernel<T, RAW>), dim3(xcd_grid(nrt, w.L.n2p / T::BN), w.L.b), dim3(T::THREADS),
                    (smem_bytes<T>()), s, w.MDT, w.MD, conf, w.rowpart, w.colpart, w.L, scale);
 }
 
 void launch_score_exp(const Workspace& w, float* conf, float scale, int shifted, hipStream_t s, ProfileHook* hk) {
-    if (shifted) launch_score_t<ScoreTileW8, true>(w, conf, scale, s, hk);
+    const bool sq = score_square();
+    if (shifted && sq) launch_score_t<ScoreTileSq, true>(w, conf, scale, s, hk);
+    else if (shifted) launch_score_t<ScoreTileW8, true>(w, conf, scale, s, hk);
+    else if (sq) launch_score_t<ScoreTileSq, false>(w, conf, scale, s, hk);
     else launch_score_t<ScoreTileW8, false>(w, conf, scale, s, hk);
 }
 

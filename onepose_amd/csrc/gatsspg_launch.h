@@ -51,7 +51,8 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
 void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 // shifted = 0: E = exp(S) into conf + row/col sum partials (|S| <= 80); 1: raw scores S into conf (max-subtracting path)
 void launch_score_exp(const Workspace& w, float* conf, float scale, int shifted, hipStream_t s, ProfileHook* hk = nullptr);
-int score_tile_rows();   // rows of a score tile = rows summed into one column partial (conf_finalize needs the count)
+int score_tile_rows();   // rows / columns of a score tile = what one column / row partial sums over (conf_finalize needs the counts)
+int score_tile_cols();
 void launch_gats_wlt(const float* W, const float* P, const Workspace& w, int add_h, hipStream_t s, ProfileHook* hk = nullptr);
 void launch_split_weights(const float* packed, unsigned short* packedb, hipStream_t s);
 

@@ -773,16 +773,17 @@ void launch_dual_softmax_match(const Workspace& w, float* conf, float scale, int
     (void)scale;
     const dim3 gf(w.cf_nch, w.cf_nst, L.b);
     const int nrt = (L.n1p + score_tile_rows() - 1) / score_tile_rows();
+    const int nct = L.n2p / score_tile_cols();
     const bool vec = (L.n2 & 3) == 0 && (reinterpret_cast<uintptr_t>(conf) & 15) == 0;
     if (shifted) {
         GATSSPG_LAUNCH(hk, KID_SOFTMAX_STATS, s, softmax_rowstat_kernel, dim3(L.n1, L.b), dim3(256), 0, s, conf, w.rshift, w.rs, L);
         GATSSPG_LAUNCH(hk, KID_SOFTMAX_STATS, s, softmax_colstat_kernel, dim3((L.n2 + 255) / 256, L.b), dim3(256), 0, s, conf,
                        w.cshift, w.cs, L);
     }
-    const bool small = w.sc_nct <= 128 && nrt <= 16;
+    const bool small = nct <= 128 && nrt <= 16;
 #define GATSSPG_FINALIZE(VEC_, SH_, SM_)                                                                                     \
     GATSSPG_LAUNCH(hk, KID_CONF_FINALIZE, s, (conf_finalize_kernel<VEC_, SH_, SM_>), gf, dim3(256), 0, s, conf, w.rowpart,    \
-                   w.colpart, w.rs, w.cs, w.rshift, w.cshift, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, L, w.sc_nct, nrt,       \
+                   w.colpart, w.rs, w.cs, w.rshift, w.cshift, w.rmax_v, w.rmax_i, w.cmax_v, w.cmax_i, L, nct, nrt,            \
                    w.cf_nch, w.cf_nst)
     if (vec && !shifted && small) GATSSPG_FINALIZE(true, false, true);
     else if (vec && !shifted) GATSSPG_FINALIZE(true, false, false);
