@@ -416,31 +416,35 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
         const unsigned short* Alo = stage + LY::A_PLANE;
         const unsigned short* Bhi = stage + 2 * LY::A_PLANE;
         const unsigned short* Blo = Bhi + LY::B_PLANE;
+        // the fragments of BOTH k16 steps of the slab are requested first (one exposed LDS latency per slab instead of one per
+        // MFMA group), then 2 x 3 products per 32x32 block, small terms first
+        bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {                             // two k16 steps per 32-wide slab
+        for (int s = 0; s < 2; ++s) {
             const int ko = 16 * s + 8 * half;                     // the same k assignment for A and B fragments
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int row = (wm * TM + tm) * 32 + l31;
-                ah[tm] = *reinterpret_cast<const bf16x8*>(Ahi + row * KS + ko);
-                al[tm] = *reinterpret_cast<const bf16x8*>(Alo + row * KS + ko);
+                ah[s][tm] = *reinterpret_cast<const bf16x8*>(Ahi + row * KS + ko);
+                al[s][tm] = *reinterpret_cast<const bf16x8*>(Alo + row * KS + ko);
             }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int col = (wn * TN + tn) * 32 + l31;
-                bh[tn] = *reinterpret_cast<const bf16x8*>(Bhi + col * KS + ko);
-                bl[tn] = *reinterpret_cast<const bf16x8*>(Blo + col * KS + ko);
+                bh[s][tn] = *reinterpret_cast<const bf16x8*>(Bhi + col * KS + ko);
+                bl[s][tn] = *reinterpret_cast<const bf16x8*>(Blo + col * KS + ko);
             }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {                 // small terms first
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][tm], bh[s][tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][tm], bl[s][tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][tm], bh[s][tn], acc[tm][tn], 0, 0, 0);
                 }
-        }
     };
     unsigned short* buf0 = smem;
     unsigned short* buf1 = smem + LY::STAGE;

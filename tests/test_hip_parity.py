@@ -345,6 +345,20 @@ def test_n3d_not_multiple_of_4_scalar_finalize_path():
     np.testing.assert_array_equal(m1.cpu().numpy(), inter["batched"]["matches1"])
 
 
+def test_many_query_points_takes_the_looped_finalize_prologue():
+    """n1 > 2048 (more than 16 row tiles of the score kernel) and n2 > 8192 (more than 128 column tiles) leave the straight-line
+    prologue of conf_finalize for the looped one; both against the oracle."""
+    sd = synthetic.make_state_dict(7)
+    hp = dict(HP, match_threshold=0.0)
+    for n1, n2 in ((2300, 260), (140, 8450)):
+        data = synthetic.make_inputs(b=1, n1=n1, n2=n2, num_leaf=8, seed=37)
+        _, conf_ref, inter = orc.forward(sd, data, hp, return_intermediates=True)
+        conf, m0, m1, s0, s1 = make_model(sd, hp).forward_batched(to_dev(data))
+        assert maxdiff(conf.cpu().numpy(), conf_ref) < CONF_ATOL, (n1, n2)
+        np.testing.assert_array_equal(m0.cpu().numpy(), inter["batched"]["matches0"])
+        np.testing.assert_array_equal(m1.cpu().numpy(), inter["batched"]["matches1"])
+
+
 def test_frames_in_flight_on_separate_streams_match_serial():
     """Three frames enqueued concurrently on three HIP streams (own workspace/outputs, shared weights)
     give bit-identical results to running them one after the other -- the bench's throughput mode."""
