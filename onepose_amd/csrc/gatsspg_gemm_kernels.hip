@@ -488,37 +488,47 @@ __global__ __launch_bounds__(T::THREADS) void mlp3_kernel(const float* __restric
 //     in-block reduction.  Query-side tiles additionally leave point-major (MDT [b][n1p][256], 1 KiB rows): the score
 //     GEMM then reads its A operand row-major like a weight matrix (b128 fragment reads) instead of [K][M].
 // =====================================================================================================
-using FinalTile = GemmTile<256, 32, 4, 1, false>;
+using FinalTile = GemmTile<256, 32, 8, 1, false>;   // 8 waves x one 32x32 tile (4 waves x 64x32 left one wave per SIMD: 15.0 us)
 
-__global__ __launch_bounds__(256) void final_proj_norm_kernel(const float* __restrict__ Wf, const float* __restrict__ bf,
+__global__ __launch_bounds__(FinalTile::THREADS) void final_proj_norm_kernel(const float* __restrict__ Wf, const float* __restrict__ bf,
                                                               const float* __restrict__ Z, float* __restrict__ MD,
                                                               float* __restrict__ MDT, ColLayout L) {
     using T = FinalTile;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ float npart[4][32];
+    __shared__ float npart[T::WM][32];
     const int ct = blockIdx.x;
     const int c0 = ct * T::BN, ld = L.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    float bias[T::TM][16];   // requested before the main loop
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const vf4 b4 = ldg4(bf + (wave * T::TM + tm) * 32 + 8 * k + 4 * half);
+            bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
+        }
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     gemm_mainloop<T>(
         acc, smem, D / BK, [&](int kt) { return Wf + kt * BK; }, D,
         [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, l31 = lane & 31;
     float ss = 0.f;
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = wave * 64 + tm * 32 + mfma_row(r, half);
-            const float v = acc[tm][0][r] + bf[row];
+            const float v = acc[tm][0][r] + bias[tm][r];
             acc[tm][0][r] = v;
             ss += v * v;
         }
     ss += __shfl_xor(ss, 32);
     if (half == 0) npart[wave][l31] = ss;
     __syncthreads();
-    const float nrm = sqrtf((npart[0][l31] + npart[1][l31]) + (npart[2][l31] + npart[3][l31]));
+    float n2 = npart[0][l31];
+#pragma unroll
+    for (int w = 1; w < T::WM; ++w) n2 += npart[w][l31];   // fixed order
+    const float nrm = sqrtf(n2);
     const float inv = 1.f / fmaxf(nrm, 1e-12f);
     const TileSeg ts = tile_seg(L, c0, T::BN);   // 32-column tiles never straddle a segment (segments are multiples of 128)
     constexpr int TS = D + 4;                    // point-major staging tile [32][260]
@@ -526,7 +536,7 @@ __global__ __launch_bounds__(256) void final_proj_norm_kernel(const float* __res
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = wave * 64 + tm * 32 + mfma_row(r, half);
+            const int row = (wave * T::TM + tm) * 32 + mfma_row(r, half);
             const float v = acc[tm][0][r] * inv;
             MD[(size_t)row * ld + c0 + l31] = v;
             if (ts.side == 0) smem[l31 * TS + row] = v;   // block-uniform branch; the main loop ended on a barrier
@@ -534,7 +544,8 @@ __global__ __launch_bounds__(256) void final_proj_norm_kernel(const float* __res
     if (ts.side == 0) {
         __syncthreads();
         float* dst = MDT + ((size_t)ts.frame * L.n1p + (c0 - ts.seg_start)) * D;
-        for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
+#pragma unroll
+        for (int idx = tid; idx < 32 * (D / 4); idx += T::THREADS) {
             const int pt = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
             *reinterpret_cast<vf4*>(dst + (size_t)pt * D + c4) = *reinterpret_cast<const vf4*>(smem + pt * TS + c4);
         }
@@ -790,7 +801,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
 
 void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     allow_big_lds<final_proj_norm_kernel>();
-    GATSSPG_LAUNCH(hk, KID_FINAL_PROJ, s, final_proj_norm_kernel, dim3(w.L.ld / FinalTile::BN), dim3(256),
+    GATSSPG_LAUNCH(hk, KID_FINAL_PROJ, s, final_proj_norm_kernel, dim3(w.L.ld / FinalTile::BN), dim3(FinalTile::THREADS),
                    (smem_bytes<FinalTile>()), s, Wf, bf, w.Z, w.MD, w.MDT, w.L);
 }
 

@@ -456,12 +456,14 @@ def test_lightning_style_wrapper_on_gpu(tmp_path):
 # ----------------------------------------------------------------------------------------------------
 # amortised mode: per-object database cache
 # ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("b,n2,flags_hp", [(1, 500, {}), (2, 257, {}), (1, 130, {"with_linear_transform": True, "additional": True})])
-def test_database_cache_is_bit_identical_to_plain_forward(b, n2, flags_hp):
-    """prepare_database + forward(database=...) == forward, bit for bit, for several query sizes against ONE cache."""
+def test_database_cache_is_bit_identical_to_plain_forward(b, n2, flags_hp, precision):
+    """prepare_database + forward(database=...) == forward, bit for bit, for several query sizes against ONE cache (the cache
+    is built and used under the module's own flags / precision)."""
     sd = synthetic.make_state_dict(8)
     hp = dict(HP, match_threshold=0.0, **flags_hp)
-    model = make_model(sd, hp)
+    model = make_model(sd, hp, precision)
     base = to_dev(synthetic.make_inputs(b, 64, n2, 8, seed=60))
     db = model.prepare_database(base)
     for n1, seed in ((64, 61), (200, 62), (131, 63)):
@@ -485,6 +487,10 @@ def test_database_cache_rejects_mismatch():
     db_other = model.prepare_database(other)
     with pytest.raises(ValueError, match="database cache was built for"):
         model.engine.forward(other["descriptors2d_query"], other["descriptors3d_db"], other["descriptors2d_db"], 0.07, 0.2, db)
+    model.precision = "bf16x3"            # the cache was built in fp32: a precision switch makes it stale too
+    with pytest.raises(ValueError, match="different weights"):
+        model(base, database=db)
+    model.precision = "fp32"
     with torch.no_grad():
         model.final_proj.bias.add_(1.0)   # weights change -> cache is stale
     with pytest.raises(ValueError, match="different weights"):
