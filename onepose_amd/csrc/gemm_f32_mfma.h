@@ -77,26 +77,6 @@ __device__ __forceinline__ vf4 ldg4u_off(const float* base, unsigned byte_off) {
 }
 
 
-// N x { 1 MFMA, 1 instruction of class MASK }  (LLVM SchedGroupMask: 0x8 MFMA, 0x2 VALU, 0x20 VMEM read,
-// 0x100 DS read, 0x200 DS write)
-template <int N, int MASK>
-__device__ __forceinline__ void sched_interleave() {
-    if constexpr (N > 0) {
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(MASK, 1, 0);
-        sched_interleave<N - 1, MASK>();
-    }
-}
-template <int N>
-__device__ __forceinline__ void sched_interleave_vmem() {
-    if constexpr (N > 0) {
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
-        sched_interleave_vmem<N - 1>();
-    }
-}
-
 // ABLATE (profiling only, wrong results): 1 = no global loads in the steady-state loop,
 //   2 = no global loads and no LDS writes, 3 = steady-state loop cut to one step pair,
 //   6 = every load of a wave hits the same 1 KiB (always L1-hot)
@@ -106,7 +86,6 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
                                                  BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform,
                                                  BCol bcol = BCol()) {
     constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN;
-    constexpr bool FINE_INTERLEAVE = false;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -211,60 +190,35 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     auto step = [&](const float* cur, float* nxt, int kt_load, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC],
                     float2(&rx)[T::B_VEC]) {
         float a0[TM][8], b0[TN][8], a1[TM][8], b1[TN][8];
-        if constexpr (FINE_INTERLEAVE) {
-            // ONE scheduling region; sched_group_barrier asks for at most one memory instruction in the
-            // shadow of each MFMA.  Measured on mlp0 (128x64 tile): a workgroup alone on its CU 23.1 -> 21.1 us,
-            // but two co-resident workgroups 37.0 -> 40.2 us, so this is off by default.
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(cur, 0, a0, b0);
-            read_frags(cur, 1, a1, b1);
-            if constexpr (ABLATE <= 1) swrite(nxt, ra, rb, rx);
-            if constexpr (ABLATE == 0 || ABLATE == 6) gload(kt_load, ra, rb, rx);
-            mfma4(a0, b0, 0);
-            mfma4(a0, b0, 4);
-            mfma4(a1, b1, 0);
-            mfma4(a1, b1, 4);
-            constexpr int NMFMA = 16 * TM * TN;
-            constexpr int NRD = (T::AKM ? TM * 8 : TM * 2) + TN * 4;   // fragment-read instructions per half slab
-            constexpr int NWR = ABLATE <= 1 ? T::A_VEC + T::B_VEC : 0;
-            constexpr int NLD = ABLATE == 0 ? T::A_VEC + T::B_VEC : 0;
-            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-            sched_interleave<NRD < NMFMA ? NRD : NMFMA, 0x100>();
-            sched_interleave<(NRD + NWR <= NMFMA) ? NWR : 0, 0x200>();
-            sched_interleave_vmem<(NRD + NWR + NLD <= NMFMA) ? NLD : 0>();
-            __builtin_amdgcn_sched_group_barrier(0x8, NMFMA, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            // Eight MFMA groups (2 k-steps each) with the memory work of the step placed between them (a 32x32x2
-            // f32 MFMA occupies the matrix pipe for 64 cycles while the wave may issue independent instructions);
-            // sched_barrier(0) between the groups keeps hipcc from regrouping them.  The global loads are NOT
-            // issued as one burst: measured on mlp0, loads that hit L1 are free while L1-missing ones cost ~9 %
-            // (a burst of 6 x 8 lines per wave fills the CU's miss path and the wave blocks at the load), so the
-            // pieces are spread one or two per gap over the second half of the step.
-            constexpr int GAPS = 5;                                   // gaps 3..7 carry the loads
-            read_frags(cur, 0, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma4(a0, b0, 0, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(cur, 1, a1, b1);                               // gap 1
-            __builtin_amdgcn_sched_barrier(0);
-            mfma4(a0, b0, 2, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ABLATE <= 1 || ABLATE == 6) swrite(nxt, ra, rb, rx);   // gap 2 (frees the register set)
-            __builtin_amdgcn_sched_barrier(0);
+        // Eight MFMA groups (2 k-steps each) with the memory work of the step placed between them (a 32x32x2
+        // f32 MFMA occupies the matrix pipe for 64 cycles while the wave may issue independent instructions);
+        // sched_barrier(0) between the groups keeps hipcc from regrouping them.  The global loads are NOT
+        // issued as one burst: measured on mlp0, loads that hit L1 are free while L1-missing ones cost ~9 %
+        // (a burst of 6 x 8 lines per wave fills the CU's miss path and the wave blocks at the load), so the
+        // pieces are spread one or two per gap over the second half of the step.
+        constexpr int GAPS = 5;                                   // gaps 3..7 carry the loads
+        read_frags(cur, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(a0, b0, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(cur, 1, a1, b1);                               // gap 1
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(a0, b0, 2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ABLATE <= 1 || ABLATE == 6) swrite(nxt, ra, rb, rx);   // gap 2 (frees the register set)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < 6; ++g) {                             // MFMA groups 3..8, gaps 3..7 between them
-                if (g < 2) mfma4(a0, b0, 4 + 2 * g, 2);
-                else mfma4(a1, b1, 2 * (g - 2), 2);
-                __builtin_amdgcn_sched_barrier(0);
-                if (g < GAPS) {
-                    if constexpr (ABLATE == 0 || ABLATE == 6) {
+        for (int g = 0; g < 6; ++g) {                             // MFMA groups 3..8, gaps 3..7 between them
+            if (g < 2) mfma4(a0, b0, 4 + 2 * g, 2);
+            else mfma4(a1, b1, 2 * (g - 2), 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g < GAPS) {
+                if constexpr (ABLATE == 0 || ABLATE == 6) {
 #pragma unroll
-                        for (int q = 0; q < NPIECE; ++q)
-                            if (q % GAPS == g) gload_piece(kt_load, q, ra, rb, rx);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int q = 0; q < NPIECE; ++q)
+                        if (q % GAPS == g) gload_piece(kt_load, q, ra, rb, rx);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
