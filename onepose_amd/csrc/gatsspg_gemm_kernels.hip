@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict
 // =====================================================================================================
 // tiles (one InstanceNorm partial per 64-column tile whatever BN is)
 using Mlp0TileW8 = GemmTile<128, MLP0_BN, 4, 2, false>;       // both arithmetics: 8 waves, one 32x32 MFMA tile each (fp32: 43.1 vs 45.0 us on 4 waves)
+using Mlp0TileW16 = GemmTile<128, 2 * MLP0_BN, 4, 4, false>;  // fp32 alternative (tuning builds): 128x128 on 16 waves, one workgroup per CU
 using Mlp0TileB8 = GemmTile<128, 2 * MLP0_BN, 2, 4, false>;   // split-bf16 alternative (tuning builds): 128x128 on 8 waves (kernel -4 %, frames/s equal)
 
 // per-workgroup timeline of mlp0_kernel (tools/trace_mlp0.py): 8 x u64 per workgroup
@@ -788,6 +789,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else if (t0 == 15) launch_mlp0_t<Mlp0TileW8, 5, 0>(W0, b0, wb, w, s, hk);   // all workgroups stream the same (cache-hot) panels
     else if (t0 == 16) launch_mlp0_t<Mlp0TileW8, 6, 0>(W0, b0, wb, w, s, hk);   // every load L1-hot
 #endif
+    else if (t0 == 2) launch_mlp0_t<Mlp0TileW16, 0, 0>(W0, b0, wb, w, s, hk);
     else launch_mlp0_t<Mlp0TileW8, 0, 0>(W0, b0, wb, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
     if (w.prec == 1 && t3 == 0) launch_mlp3_t<Mlp3Tile, 0, 1>(W3, b3, wb, w, s, hk);

@@ -39,13 +39,13 @@ struct GemmTile {
     static constexpr int B_FLOATS = BK * BN;
     static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
     static constexpr int SMEM_FLOATS = 2 * STAGE_FLOATS;
-    static constexpr int THREADS = 64 * WM * WN;       // 4 waves (256 threads) or 8 waves (512 threads)
+    static constexpr int THREADS = 64 * WM * WN;       // 4, 8 or 16 waves
     static constexpr int A_VEC = BM * BK / 4 / THREADS;   // float4 per thread per slab
     static constexpr int B_PIECES = BK * BN / 4;          // float4 pieces of a B slab
     // a narrow tile on many waves has fewer B pieces than threads: every thread still moves one piece, the surplus threads
     // duplicate the piece of thread (tid mod B_PIECES) -- same bytes to the same LDS address, no guarded loads
     static constexpr int B_VEC = B_PIECES >= THREADS ? B_PIECES / THREADS : 1;
-    static_assert(WM * WN == 4 || WM * WN == 8, "workgroup = 4 or 8 waves");
+    static_assert(WM * WN == 4 || WM * WN == 8 || WM * WN == 16, "workgroup = 4, 8 or 16 waves");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
     static_assert(A_VEC >= 1 && (B_PIECES % THREADS == 0 || THREADS % B_PIECES == 0), "tile / workgroup mismatch");
 };
