@@ -501,7 +501,7 @@ def test_database_cache_rejects_mismatch():
 # ----------------------------------------------------------------------------------------------------
 # randomized shapes / flags
 # ----------------------------------------------------------------------------------------------------
-def _random_cases(n=14, seed=2024):
+def _random_cases(n=24, seed=2024):
     rs = np.random.RandomState(seed)
     cases = []
     for i in range(n):
@@ -510,23 +510,26 @@ def _random_cases(n=14, seed=2024):
         n2 = int(rs.choice([2, 5, 31, 64, 100, 127, 128, 129, 255, 257, 400, 515]))
         L = int(rs.choice([8, 8, 8, 1, 2, 5, 13]))
         flags = int(rs.choice([1, 1, 1, 0, 3, 4, 5, 7]))
-        cases.append((i, b, n1, n2, L, flags))
+        if i >= 14:   # round 2: larger shapes that straddle the finalize chunks (512 columns) and strips (16 rows), both arithmetics
+            n1 = int(rs.choice([130, 513, 777, 1025]))
+            n2 = int(rs.choice([511, 513, 1030, 1537, 2049]))
+        cases.append((i, b, n1, n2, L, flags, "bf16x3" if i % 3 == 2 else "fp32"))
     return cases
 
 
-@pytest.mark.parametrize("i,b,n1,n2,L,flags", _random_cases())
-def test_random_shapes_vs_oracle(i, b, n1, n2, L, flags):
+@pytest.mark.parametrize("i,b,n1,n2,L,flags,precision", _random_cases())
+def test_random_shapes_vs_oracle(i, b, n1, n2, L, flags, precision):
     sd = synthetic.make_state_dict(100 + i)
     data = synthetic.make_inputs(b=b, n1=n1, n2=n2, num_leaf=L, seed=200 + i)
     hp = dict(HP, match_threshold=0.0, include_self=bool(flags & 1), additional=bool(flags & 2),
               with_linear_transform=bool(flags & 4))
     _, conf_ref, inter = orc.forward(sd, data, hp, return_intermediates=True)
-    conf, m0, m1, s0, s1 = make_model(sd, hp).forward_batched(to_dev(data))
+    conf, m0, m1, s0, s1 = make_model(sd, hp, precision).forward_batched(to_dev(data))
     cn = conf.cpu().numpy()
     # tiny point counts make InstanceNorm ill-conditioned (see two_points): scale the tolerance there
     tol = CONF_ATOL if min(n1, n2) >= 17 else 5e-3
     assert maxdiff(cn, conf_ref) < tol, (b, n1, n2, L, flags)
-    if min(n1, n2) >= 17:
+    if min(n1, n2) >= 17 and precision == "fp32":   # (bf16x3 near-ties: see the benchmarked-shape test)
         np.testing.assert_array_equal(m0.cpu().numpy(), inter["batched"]["matches0"])
         np.testing.assert_array_equal(m1.cpu().numpy(), inter["batched"]["matches1"])
     # always: outputs self-consistent with the reference's matching logic applied to the returned conf
