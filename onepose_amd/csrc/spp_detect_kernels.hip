@@ -464,14 +464,25 @@ __global__ __launch_bounds__(256) void sample_kernel(DescView dv, int Hc, int Wc
     const float* base = dv.p + (size_t)im * dv.istride + dv.origin;
     float v[16];
     float ss = 0.f;
+    // 8 channels x 4 taps = 32 gathers requested before any is used (written as one fmaf chain per channel hipcc waited for
+    // every gather -- s_waitcnt vmcnt(0) -- before issuing the next: 64 dependent L2 round trips per thread)
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const float* pc = base + (size_t)(grp * 16 + k) * dv.cstride;
-        float a = 0.f;
+    for (int k0 = 0; k0 < 16; k0 += 8) {
+        float t[8][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a = fmaf(pc[off[q]], wq[q], a);
-        v[k] = a;
-        ss = fmaf(a, a, ss);
+        for (int k = 0; k < 8; ++k) {
+            const float* pc = base + (size_t)(grp * 16 + k0 + k) * dv.cstride;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[k][q] = pc[off[q]];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a = fmaf(t[k][q], wq[q], a);
+            v[k0 + k] = a;
+            ss = fmaf(a, a, ss);
+        }
     }
     part[grp][kl] = ss;
     __syncthreads();
