@@ -115,8 +115,8 @@ int gatsspg_forward_profiled(const float* packed, const float* desc2d_query, con
 /* ---- amortised mode: per-object database cache ------------------------------------
  * The 3D database (desc3d_db + its leaves desc2d_db) is constant per object (inference.py:113-130) while the
  * reference recomputes -- and re-uploads, inference.py:86-90 -- everything per frame.  gnn.layers.0 (GATs),
- * the 3D side of gnn.layers.1 (self) and the 3D-side projections / KV sums of gnn.layers.2 (cross) do not depend
- * on the query frame; gatsspg_prepare_database computes them once, gatsspg_forward_cached skips them.  Results are
+ * the 3D side of gnn.layers.1 (self), the 3D-side projections / KV sums of gnn.layers.2 (cross) and the leaf logits
+ * of the later GATs layers (num_leaf == 8, no linear transform) do not depend on the query frame; gatsspg_prepare_database computes them once, gatsspg_forward_cached skips them.  Results are
  * bit-identical to gatsspg_forward (same kernels, same fixed-order reductions).  The cache does not depend on n1.
  * ws for prepare: at least gatsspg_workspace_bytes(b, 2, n2, num_leaf). */
 size_t gatsspg_db_cache_bytes(int b, int n2);

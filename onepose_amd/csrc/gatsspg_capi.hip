@@ -70,7 +70,8 @@ const float* gats_w(const float* packed, int layer) { return packed + PW_GATS + 
 
 // h3 / dq: fused state load (see launch_gats); only valid when gats_fuses_state_load() says so
 void enqueue_gats(const float* packed, int layer, const float* desc2d_db, int num_leaf, int flags, const Workspace& w,
-                  hipStream_t s, ProfileHook* hk = nullptr, const float* h3 = nullptr, const float* dq = nullptr) {
+                  hipStream_t s, ProfileHook* hk = nullptr, const float* h3 = nullptr, const float* dq = nullptr,
+                  const float* cached_logits = nullptr) {
     const float* g = gats_w(packed, layer);
     if (flags & GATSSPG_FLAG_WITH_LINEAR_TRANSFORM) {
         // pre-activation aggregate -> MSG (free between attention layers), then elu(W^T pre (+h))
@@ -78,7 +79,7 @@ void enqueue_gats(const float* packed, int layer, const float* desc2d_db, int nu
         const int add_h = (flags & GATSSPG_FLAG_INCLUDE_SELF) && (flags & GATSSPG_FLAG_ADDITIONAL);
         launch_gats_wlt(g + GatsW::W, w.MSG, w, add_h, s, hk);
     } else {
-        launch_gats(g + GatsW::U1, g + GatsW::U2, desc2d_db, num_leaf, flags, w.Z, w, s, hk, h3, dq);
+        launch_gats(g + GatsW::U1, g + GatsW::U2, desc2d_db, num_leaf, flags, w.Z, w, s, hk, h3, dq, cached_logits);
     }
 }
 
@@ -91,9 +92,11 @@ void enqueue_attn(const float* packed, int layer, int kind, const Workspace& w, 
 }
 
 // ---- database cache: everything of the first three GNN layers that depends only on the
-//      per-object 3D database.  Layout (floats): Y2 [b][256][n2] | QY [b][256][n2] | kvY [b][4][KVP]
+//      per-object 3D database.  Layout (floats): Y2 [b][256][n2] | QY [b][256][n2] | kvY [b][4][KVP] |
+//      LL [3][b][tiles][32] (leaf logits of GATs layers 1..3; layer 0 is inside Y2)
 struct DbCache {
-    float *Y2, *QY, *kvY;
+    float *Y2, *QY, *kvY, *LL;
+    size_t ll_layer;   // floats per layer of LL
     size_t bytes;
 };
 DbCache carve_cache(void* base, int b, int n2) {
@@ -103,7 +106,9 @@ DbCache carve_cache(void* base, int b, int n2) {
     c.Y2 = p;
     c.QY = p ? p + plane : nullptr;
     c.kvY = p ? p + 2 * plane : nullptr;
-    c.bytes = sizeof(float) * (2 * plane + (size_t)b * H * KVP);
+    c.LL = p ? p + 2 * plane + (size_t)b * H * KVP : nullptr;
+    c.ll_layer = gats_leaf_logit_floats(b, n2);
+    c.bytes = sizeof(float) * (2 * plane + (size_t)b * H * KVP + 3 * c.ll_layer);
     return c;
 }
 Workspace windowed(const Workspace& w, int side) {
@@ -283,6 +288,8 @@ int gatsspg_prepare_database(const float* packed, const float* desc3d_db, const 
     if (hipMemcpy2DAsync(c.kvY, sizeof(float) * H * KVP, w.kvfin + (size_t)H * KVP, sizeof(float) * 2 * H * KVP,
                          sizeof(float) * H * KVP, b, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return fail("prepare_database: copy of the KV sums failed");
+    if (gats_caches_leaf_logits(num_leaf, flags))   // leaf . u1 of the three GATs layers still to come
+        launch_gats_leaf_logits(gats_w(packed, 1) + GatsW::U1, GatsW::SIZE, 3, desc2d_db, c.LL, w, s);
     return check_launch("prepare_database");
 }
 
@@ -309,8 +316,10 @@ int gatsspg_forward_cached(const float* packed, const float* desc2d_query, const
         return fail("forward_cached: copy of the KV sums failed");
     launch_attn_apply(w, 1, s);
     launch_mlp(a1 + AttnW::W0, a1 + AttnW::B0, a1 + AttnW::W3, a1 + AttnW::B3, attn_wb(packed, 1), w, s);
+    const bool cached_logits = gats_caches_leaf_logits(num_leaf, flags);
     for (int t = 1; t < 4; ++t) {
-        enqueue_gats(packed, t, desc2d_db, num_leaf, flags, w, s);
+        enqueue_gats(packed, t, desc2d_db, num_leaf, flags, w, s, nullptr, nullptr, nullptr,
+                     cached_logits ? c.LL + (size_t)(t - 1) * c.ll_layer : nullptr);
         enqueue_attn(packed, 2 * t, GATSSPG_LAYER_SELF, w, s);
         enqueue_attn(packed, 2 * t + 1, GATSSPG_LAYER_CROSS, w, s);
     }

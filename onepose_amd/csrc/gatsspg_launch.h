@@ -65,7 +65,13 @@ void launch_store_state(const float* src, float* out2d, float* out3d, const Work
 // [b,256,n2] tensor (first layer of a forward: the state load is fused, `dq` is copied into the 2D side by spare workgroups)
 void launch_gats(const float* u1, const float* u2, const float* leaves, int num_leaf, int flags, float* dst,
                  const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr, const float* h3 = nullptr,
-                 const float* dq = nullptr);
+                 const float* dq = nullptr, const float* cached_logits = nullptr);
+// per-object cache of the leaf logits (amortised mode): [nlayers][b][tiles][32] floats, gats_leaf_logit_floats per layer;
+// launch_gats(..., cached_logits = that layer's block) then skips the leaf . u1 products
+bool gats_caches_leaf_logits(int num_leaf, int flags);
+size_t gats_leaf_logit_floats(int b, int n2);
+void launch_gats_leaf_logits(const float* u1_first, int u1_stride, int nlayers, const float* leaves, float* cl,
+                             const Workspace& w, hipStream_t s);
 // true if launch_gats can take h3 / dq for this configuration (fused state load)
 bool gats_fuses_state_load(int num_leaf, int flags, const Workspace& w);
 void launch_dual_softmax_match(const Workspace& w, float* conf, float scale, int shifted, float match_threshold,

@@ -104,11 +104,35 @@ __device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : 0.2f * 
 // what load_state_kernel would have done in a launch of its own.
 constexpr int GATS_COPY_BLOCKS = 64;   // 4 channel rows each
 
-template <bool FUSED_LOAD>
+// leaf logits of one lane: its 4 leaves x its 8 channel rows, then over the 8 row lanes (lane bits 3..5) with two halving
+// exchanges and one butterfly step: afterwards a lane holds leaf ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1) of its 16-byte
+// piece, summed over this wave's 64 channel rows.  ONE function for the layer kernel and for the per-object logit cache
+// (gats_leaf_logits_kernel): the cached values are the bits the layer kernel would have computed.
+__device__ __forceinline__ float leaf_logit_wave_partial(const float4 (&v)[8], const float (&u1r)[8], int lane) {
+    float dl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        dl[0] += v[p].x * u1r[p]; dl[1] += v[p].y * u1r[p]; dl[2] += v[p].z * u1r[p]; dl[3] += v[p].w * u1r[p];
+    }
+    const bool b3 = lane & 8, b4 = lane & 16;
+    float k0 = b3 ? dl[2] : dl[0], k1 = b3 ? dl[3] : dl[1];
+    k0 += __shfl_xor(b3 ? dl[0] : dl[2], 8);
+    k1 += __shfl_xor(b3 ? dl[1] : dl[3], 8);
+    float s = b4 ? k1 : k0;
+    s += __shfl_xor(b4 ? k0 : k1, 16);
+    s += __shfl_xor(s, 32);
+    return s;
+}
+__device__ __forceinline__ int leaf_logit_slot(int lane) { return (lane & 7) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1); }
+
+// CACHED_LOGITS: the leaf logits come from the per-object cache `cl` ([tiles][32] floats of this frame and layer) instead of
+// being recomputed from the leaves (amortised mode)
+template <bool FUSED_LOAD, bool CACHED_LOGITS>
 __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __restrict__ u1, const float* __restrict__ u2,
                                                            const float* __restrict__ leaves, const float* Z, float* dst,
                                                            ColLayout L, int flags, int raw_out, int ntiles,
-                                                           const float* __restrict__ h3, const float* __restrict__ dq) {
+                                                           const float* __restrict__ h3, const float* __restrict__ dq,
+                                                           const float* __restrict__ cl) {
     __shared__ __attribute__((aligned(16))) float hs[D * 4];
     __shared__ __attribute__((aligned(16))) float pre[D * 4];
     __shared__ float red3[4][4];
@@ -168,6 +192,8 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
         a = *reinterpret_cast<const float4*>(Z + (size_t)tid * L.ld + ycol);
     }
     const float u2v = u2[tid];
+    float clv = 0.f;
+    if (CACHED_LOGITS && tid < 32) clv = cl[((size_t)f * ntiles + tile) * 32 + tid];
     // UNCONDITIONAL loads: lanes of points beyond n2 (last tile only) re-read point 0 of the tile -- finite values whose
     // results are never stored.  (A `valid ? load : 0` form compiles to exec-masked branches with an s_waitcnt vmcnt(0)
     // in the middle of the sequence: the 8 loads of a lane were in flight 3 + 5 instead of 8 at a time.)
@@ -178,7 +204,7 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
     for (int p = 0; p < 8; ++p) {
         const int ch = p * 32 + w * 8 + r;
         v[p] = *reinterpret_cast<const float4*>(Lf + (size_t)ch * lrow + 4 * c4l);
-        u1r[p] = u1[ch];
+        u1r[p] = CACHED_LOGITS ? 0.f : u1[ch];
     }
 #ifdef GATSSPG_PROFILING_BUILD
     if (raw_out == 2) {   // read-only probe (profiling builds, wrong results): the leaf stream alone, one 4-byte store per thread
@@ -205,22 +231,11 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
         for (int o = 4; o <= 32; o <<= 1) s += __shfl_xor(s, o);
         if (lane < 4) red3[w][(lane & 1) * 2 + (lane >> 1)] = s;
     }
-    {
-        // leaf logits: this lane's 4 leaves x its 8 channel rows, then over the 8 row lanes (lane bits 3..5) the same way:
-        // after two halving exchanges a lane holds leaf ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1) of its 16-byte piece
-        float dl[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            dl[0] += v[p].x * u1r[p]; dl[1] += v[p].y * u1r[p]; dl[2] += v[p].z * u1r[p]; dl[3] += v[p].w * u1r[p];
-        }
-        const bool b3 = lane & 8, b4 = lane & 16;
-        float k0 = b3 ? dl[2] : dl[0], k1 = b3 ? dl[3] : dl[1];
-        k0 += __shfl_xor(b3 ? dl[0] : dl[2], 8);
-        k1 += __shfl_xor(b3 ? dl[1] : dl[3], 8);
-        float s = b4 ? k1 : k0;
-        s += __shfl_xor(b4 ? k0 : k1, 16);
-        s += __shfl_xor(s, 32);
-        if (lane < 32) redl[w][c4 * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1)] = s;
+    if (CACHED_LOGITS) {
+        if (tid < 32) redl[0][tid] = clv;
+    } else {
+        const float s = leaf_logit_wave_partial(v, u1r, lane);
+        if (lane < 32) redl[w][leaf_logit_slot(lane)] = s;
     }
     __syncthreads();
     if (tid < 4) {
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = tid * 8 + j;
-            e[1 + j] = lrelu02(s3 + ((redl[0][c] + redl[1][c]) + (redl[2][c] + redl[3][c])));
+            e[1 + j] = lrelu02(s3 + (CACHED_LOGITS ? redl[0][c] : (redl[0][c] + redl[1][c]) + (redl[2][c] + redl[3][c])));
         }
         float m = include_self ? e[0] : e[1];
 #pragma unroll
@@ -283,6 +298,36 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
             if (pv > 1) o[1] = o1;
             if (pv > 2) o[2] = o2;
         }
+    }
+}
+
+// Per-object leaf-logit cache: the logits leaf . u1 of GATs layers `first_layer` .. `first_layer + nlayers - 1` depend only
+// on the database (the leaves never change, GATs_SuperGlue.py:53-54), so gatsspg_prepare_database computes them once with
+// the layer kernel's own thread mapping and reduction order.  cl: [nlayers][b][tiles][32] floats.
+__global__ __launch_bounds__(256, 7) void gats_leaf_logits_kernel(const float* __restrict__ u1_first, int u1_stride, int nlayers,
+                                                                const float* __restrict__ leaves, float* __restrict__ cl,
+                                                                ColLayout L, int ntiles) {
+    __shared__ float redl[4][32];
+    const int f = blockIdx.y, tile = blockIdx.x;
+    const int n0 = tile * 4, pv = min(4, L.n2 - n0);
+    const size_t lrow = (size_t)L.n2 * 8;
+    const float* Lf = leaves + (size_t)f * D * lrow + (size_t)n0 * 8;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane >> 3, c4 = lane & 7;
+    const int c4l = (c4 >> 1) < pv ? c4 : (c4 & 1);
+    float4 v[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v[p] = *reinterpret_cast<const float4*>(Lf + (size_t)(p * 32 + w * 8 + r) * lrow + 4 * c4l);
+    for (int t = 0; t < nlayers; ++t) {
+        float u1r[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) u1r[p] = u1_first[(size_t)t * u1_stride + p * 32 + w * 8 + r];
+        const float s = leaf_logit_wave_partial(v, u1r, lane);
+        if (lane < 32) redl[w][leaf_logit_slot(lane)] = s;
+        __syncthreads();
+        if (tid < 32)
+            cl[(((size_t)t * L.b + f) * ntiles + tile) * 32 + tid] = (redl[0][tid] + redl[1][tid]) + (redl[2][tid] + redl[3][tid]);
+        __syncthreads();
     }
 }
 
@@ -361,8 +406,19 @@ bool gats_fuses_state_load(int num_leaf, int flags, const Workspace& w) {
     return num_leaf == 8 && !(flags & GATSSPG_FLAG_WITH_LINEAR_TRANSFORM) && w.L.tw_first == 0 && w.L.tw_count == w.L.np / 64;
 }
 
+bool gats_caches_leaf_logits(int num_leaf, int flags) {
+    return num_leaf == 8 && !(flags & GATSSPG_FLAG_WITH_LINEAR_TRANSFORM);
+}
+size_t gats_leaf_logit_floats(int b, int n2) { return (size_t)b * ((n2 + 3) / 4) * 32; }   // per layer
+
+void launch_gats_leaf_logits(const float* u1_first, int u1_stride, int nlayers, const float* leaves, float* cl,
+                             const Workspace& w, hipStream_t s) {
+    const int nt = (w.L.n2 + 3) / 4;
+    hipLaunchKernelGGL(gats_leaf_logits_kernel, dim3(nt, w.L.b), dim3(256), 0, s, u1_first, u1_stride, nlayers, leaves, cl, w.L, nt);
+}
+
 void launch_gats(const float* u1, const float* u2, const float* leaves, int num_leaf, int flags, float* dst,
-                 const Workspace& w, hipStream_t s, ProfileHook* hk, const float* h3, const float* dq) {
+                 const Workspace& w, hipStream_t s, ProfileHook* hk, const float* h3, const float* dq, const float* cl) {
     int raw_out = (flags & GATSSPG_FLAG_WITH_LINEAR_TRANSFORM) ? 1 : 0;
 #ifdef GATSSPG_PROFILING_BUILD
     if (tuning_knob("GATS_PROBE", 0) && !h3) raw_out = 2;   // time the leaf stream alone
@@ -372,11 +428,14 @@ void launch_gats(const float* u1, const float* u2, const float* leaves, int num_
         const int extra = h3 ? GATS_COPY_BLOCKS : 0;
         // (capping the residency -- fewer, staggered rounds of workgroups -- was measured: no gain at 4-5 per CU, worse below)
         if (h3)
-            GATSSPG_LAUNCH(hk, KID_GATS, s, gats_leaf8x4_kernel<true>, dim3(nt + extra, w.L.b), dim3(256), 0, s, u1, u2, leaves, w.Z,
-                           dst, w.L, flags, raw_out, nt, h3, dq);
+            GATSSPG_LAUNCH(hk, KID_GATS, s, (gats_leaf8x4_kernel<true, false>), dim3(nt + extra, w.L.b), dim3(256), 0, s, u1, u2,
+                           leaves, w.Z, dst, w.L, flags, raw_out, nt, h3, dq, cl);
+        else if (cl)
+            GATSSPG_LAUNCH(hk, KID_GATS, s, (gats_leaf8x4_kernel<false, true>), dim3(nt, w.L.b), dim3(256), 0, s, u1, u2, leaves,
+                           w.Z, dst, w.L, flags, raw_out, nt, h3, dq, cl);
         else
-            GATSSPG_LAUNCH(hk, KID_GATS, s, gats_leaf8x4_kernel<false>, dim3(nt, w.L.b), dim3(256), 0, s, u1, u2, leaves, w.Z, dst,
-                           w.L, flags, raw_out, nt, h3, dq);
+            GATSSPG_LAUNCH(hk, KID_GATS, s, (gats_leaf8x4_kernel<false, false>), dim3(nt, w.L.b), dim3(256), 0, s, u1, u2, leaves,
+                           w.Z, dst, w.L, flags, raw_out, nt, h3, dq, cl);
     } else {
         GATSSPG_LAUNCH(hk, KID_GATS, s, gats_generic_kernel, dim3((w.L.n2 + 3) / 4, w.L.b), dim3(256), 0, s, u1, u2, leaves,
                        w.Z, dst, w.L, num_leaf, flags, raw_out);
