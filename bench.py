@@ -508,6 +508,12 @@ CONFIGS = {
     "bf16x3": dict(b=1, n1=1000, n2=7000, precision="bf16x3", golden="head_rand",
                    what="headline shape (1000/7000, batch 1) with the attention-layer GEMMs on split-bf16 MFMA (3 bf16 products "
                         "per fp32 product); never the headline value"),
+    "bf16x6": dict(b=1, n1=1000, n2=7000, precision="bf16x6", golden="head_rand",
+                   what="headline shape (1000/7000, batch 1) with the attention-layer GEMMs on six-term split-bf16 MFMA (operands "
+                        "split exactly into 3 bf16 planes, 6 bf16 products per fp32 product: fp32-class arithmetic on the bf16 "
+                        "pipe); reported separately, never the headline value"),
+    "bf16x6-b8": dict(b=8, n1=1000, n2=7000, precision="bf16x6", golden="head_b8",
+                      what="8 frames of 1000/7000 per step, attention-layer GEMMs on six-term split-bf16 MFMA"),
     "fp32-b8": dict(b=8, n1=1000, n2=7000, precision="fp32", golden="head_b8",
                     what="BASELINE configs[2]'s per-GPU share in fp32: 8 frames of 1000/7000 per step"),
     "bf16x3-b8": dict(b=8, n1=1000, n2=7000, precision="bf16x3", golden="head_b8",
@@ -540,6 +546,29 @@ def golden_parity(runner, cfg):
     flips = int((c.argmax(2) != g["indices0_raw"]).sum() + (c.argmax(1) != g["indices1_raw"]).sum())
     return {"against": f"tests/golden/bench_{name}.npz (reference GATsSuperGlue.forward run on CPU fp32, same seeded inputs)",
             "max_abs_conf_err": err, "argmax_flips": flips, "argmax_checked": int(c.shape[0] * (c.shape[1] + c.shape[2]))}
+
+
+def side_arithmetic(device, cfg, precision, shared_inputs, K, W, S):
+    """The same workload under another GEMM arithmetic of the same entry point (a `flags` bit): frames/s with S frames in
+    flight, one frame at a time, and the parity number against the reference golden.  Reported under config, never as value."""
+    weights = Weights(device, precision)
+    slots = [Runner(device, weights, shared_inputs, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], own_stream=True) for _ in range(S)]
+    for i in range(W):
+        slots[i % S].step(i)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(K):
+        slots[i % S].step(i)
+    torch.cuda.synchronize(device)
+    inflight = K * cfg["b"] / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for i in range(K):
+        slots[0].step(i)
+    torch.cuda.synchronize(device)
+    single = K * cfg["b"] / (time.perf_counter() - t0)
+    par = golden_parity(slots[0], cfg)
+    return {"frames_per_sec": round(inflight, 2), "single_stream_frames_per_sec": round(single, 2),
+            "max_abs_conf_err_vs_reference_golden": par and par["max_abs_conf_err"], "argmax_flips_vs_reference_golden": par and par["argmax_flips"]}
 
 
 def self_launch(args, argv):
@@ -589,6 +618,8 @@ def main():
     ap.add_argument("--tuning-lib", action="store_true",
                     help="load lib*_tuning.so (python -m onepose_amd.build_ext --tuning): GATSSPG_<KNOB> environment knobs select "
                          "alternative tile shapes for A/B runs; the line is labelled and is never a headline number")
+    ap.add_argument("--no-side-arithmetics", action="store_true",
+                    help="headline config: skip the extra bf16x6 / bf16x3 passes reported under config.other_gemm_arithmetics")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: stub steps on CPU over gloo -- tests the --gpus N launcher, barrier, metrics gather and JSON line")
     args = ap.parse_args()
@@ -699,6 +730,12 @@ def main():
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))   # conservative: contains part of the event packets' latency
     pair_ms = float(np.median([c0.elapsed_time(c1) for c0, c1 in cal]))
 
+    # the other two arithmetics of the attention-layer GEMMs on the same workload (rank 0, headline config only): same entry
+    # point, one flags bit.  bf16x6 is fp32-class (operands split exactly into three bf16 planes); bf16x3 drops to ~2^-16.
+    side = None
+    if rank == 0 and args.config == "headline" and not args.no_side_arithmetics:
+        side = {p: side_arithmetic(device, cfg, p, base.shared_inputs, K, W, S) for p in ("bf16x6", "bf16x3")}
+
     amortised = None
     if args.amortised:
         for sl in slots:
@@ -726,22 +763,24 @@ def main():
 
     if rank == 0:
         n1, n2, bsz = cfg["n1"], cfg["n2"], runner.b
-        split = cfg["precision"] == "bf16x3" and args.kernel in ("mlp0", "qkv_kv", "mlp3")
+        nterms = {"fp32": 0, "bf16x3": 3, "bf16x6": 6}[cfg["precision"]]
+        split = nterms and args.kernel in ("mlp0", "qkv_kv", "mlp3")
         fl = kernel_flops(args.kernel, n1, n2) * bsz
         achieved = fl / (kern_ms * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        if split:                 # 3 bf16 MFMA products are issued per algorithmic flop: price the executed flops against the bf16 peak
-            achieved *= 3
+        if split:                 # 3 (6) bf16 MFMA products are issued per algorithmic flop: price the executed flops against the bf16 peak
+            achieved *= nterms
         falg = f_alg(n1, n2, NUM_LEAF)
         per = per_rank.cpu().tolist()
         fps1 = K * bsz / per[0][2] if world > 1 else value
         out = {
             "metric": "query_frames_per_sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": round(seconds / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if cfg["precision"] == "fp32" else "bf16x3", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if cfg["precision"] == "fp32" else cfg["precision"], "data": "synthetic",
             "config": {"workload": cfg["what"], "name": args.config,
                        "gemm_precision": "f32 MFMA (exact)" if cfg["precision"] == "fp32" else
-                       "split-bf16 MFMA (bf16x3) in qkv_kv / mlp0 / mlp3 via GATSSPG_FLAG_PREC_BF16X3; final_proj, score, GATs fp32",
+                       f"split-bf16 MFMA ({cfg['precision']}) in qkv_kv / mlp0 / mlp3 via GATSSPG_FLAG_PREC_{cfg['precision'].upper()}; "
+                       "final_proj, score, GATs fp32",
                        "n_2d": n1, "n_3d": n2, "num_leaf": NUM_LEAF, "batch": bsz, "steps_per_gpu": K, "frames_per_gpu": K * bsz,
                        "frames_in_flight_per_gpu": S * bsz, "timed_pass_repetitions": R,
                        "timed_pass_seconds": [round(t, 5) for t in reps], "reported": "median repetition",
@@ -774,6 +813,12 @@ def main():
             out["parity_check"] = parity
         if amortised:
             out["amortised_database_mode"] = amortised
+        if side:
+            out["config"]["other_gemm_arithmetics"] = dict(
+                side, note="same workload, same entry point, one flags bit (GATSSPG_FLAG_PREC_*); measured after the timed passes, "
+                           "never part of value.  bf16x6: every fp32 operand split EXACTLY into three bf16 planes, six bf16 MFMA "
+                           "products per fp32 product (dropped terms <= 2^-24 |ab|), fp32 accumulation: fp32-class arithmetic. "
+                           "bf16x3: two planes, three products (~2^-16 relative)")
         if world == 1 and not args.no_cpu_baseline and args.config == "headline":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -47,8 +47,13 @@ extern "C" {
  *     (tests/test_hip_parity.py runs every golden case under both modes): conf within 1e-6 abs of the fp32 forward; raw
  *     arg-max indices identical except where the reference's own top-2 entries are closer than 1e-3 relative (1-2 of
  *     64000 on the random-weight b=8 fixture, none on the others); thresholded matches identical on every fixture.
- * final_proj, the score contraction, GATs and all reductions are fp32 in both modes. */
+ *   GATSSPG_FLAG_PREC_BF16X6: six-term split-bf16 -- every fp32 operand is the EXACT sum of three bf16 terms (3 x 8 = 24
+ *     mantissa bits) and each product the six largest of the nine term products; what is dropped is <= 2^-24 |ab|, one
+ *     fp32 rounding of the product, and the accumulation is the MFMA's fp32 accumulation -- fp32-class arithmetic on the
+ *     bf16 matrix pipe (the tests hold it to the fp32 mode's own tie-gap tolerance).  The two precision bits are exclusive.
+ * final_proj, the score contraction, GATs and all reductions are fp32 in every mode. */
 #define GATSSPG_FLAG_PREC_BF16X3 0x100
+#define GATSSPG_FLAG_PREC_BF16X6 0x200
 /* layer kinds for gatsspg_attn_layer (GATs_SuperGlue.py:55-64) */
 #define GATSSPG_LAYER_SELF 0
 #define GATSSPG_LAYER_CROSS 1
@@ -88,7 +93,7 @@ size_t gatsspg_workspace_bytes(int b, int n1, int n2, int num_leaf);
 /* One-time weight preparation (replaces nothing in the reference; it is what
  * load_state_dict + .cuda() is to it).  Re-orders the q/k/v projection rows head-major, folds
  * merge into mlp.0 (W0[:,256:] @ Wm), folds W @ a[:256], W @ a[256:] of each GATs layer, and appends the bf16 hi/lo
- * planes of the three big operators of every attention layer (used by GATSSPG_FLAG_PREC_BF16X3 calls). */
+ * planes of the three big operators of every attention layer (used by GATSSPG_FLAG_PREC_BF16X3 / _BF16X6 calls). */
 int gatsspg_pack_weights(const gatsspg_raw_weights* raw, float* packed, void* stream);
 
 /* Whole forward: GATsSuperGlue.forward, GATs_SuperGlue.py:179-241, for all b samples.
@@ -142,7 +147,7 @@ int gatsspg_store_state(int which, float* out2d, float* out3d, int b, int n1, in
 int gatsspg_gats_layer(const float* packed, int layer, const float* desc2d_db, int b, int n1, int n2,
                        int num_leaf, int flags, void* ws, size_t ws_bytes, void* stream);
 /* one 'self' or 'cross' layer, both sides: AttentionalGNN.forward branch GATs_SuperGlue.py:55-64
- * = 2x AttentionPropagation.forward (:111-113) + residual; layer = 0..7; flags: only GATSSPG_FLAG_PREC_BF16X3 matters */
+ * = 2x AttentionPropagation.forward (:111-113) + residual; layer = 0..7; flags: only the GATSSPG_FLAG_PREC_* bits matter */
 int gatsspg_attn_layer(const float* packed, int layer, int kind, int b, int n1, int n2, int num_leaf,
                        int flags, void* ws, size_t ws_bytes, void* stream);
 /* final_proj + F.normalize (GATs_SuperGlue.py:209-213) */

@@ -95,7 +95,7 @@ constexpr size_t PW_FINAL_W = PW_GATS + 4 * GatsW::SIZE;
 constexpr size_t PW_FINAL_B = PW_FINAL_W + 256 * 256;
 constexpr size_t PW_TOTAL = PW_FINAL_B + 256;   // floats
 
-// Split-bf16 planes of the three big GEMM operators (GATSSPG_FLAG_PREC_BF16X3): appended to the fp32 blob, in bf16
+// Split-bf16 planes of the three big GEMM operators (GATSSPG_FLAG_PREC_BF16X3 / _BF16X6): appended to the fp32 blob, in bf16
 // elements from (unsigned short*)(packed + PW_TOTAL).  w = hi + lo with hi = RNE_bf16(w), lo = RNE_bf16(w - hi);
 // same row order as the fp32 matrices they are split from.
 struct AttnWB {
@@ -105,7 +105,11 @@ struct AttnWB {
     static constexpr size_t W0_LO = W0_HI + 512 * 512;
     static constexpr size_t W3_HI = W0_LO + 512 * 512;           // [256][512]
     static constexpr size_t W3_LO = W3_HI + 256 * 512;
-    static constexpr size_t SIZE = W3_LO + 256 * 512;
+    // third planes (GATSSPG_FLAG_PREC_BF16X6): lo2 = RNE_bf16(w - hi - lo), w = hi + lo + lo2 exactly
+    static constexpr size_t QKV_LO2 = W3_LO + 256 * 512;
+    static constexpr size_t W0_LO2 = QKV_LO2 + 768 * 256;
+    static constexpr size_t W3_LO2 = W0_LO2 + 512 * 512;
+    static constexpr size_t SIZE = W3_LO2 + 256 * 512;
 };
 constexpr size_t PWB_TOTAL = 8 * AttnWB::SIZE;                   // bf16 elements
 constexpr size_t PACKED_BYTES = sizeof(float) * PW_TOTAL + sizeof(unsigned short) * PWB_TOTAL;
@@ -113,7 +117,7 @@ constexpr size_t PACKED_BYTES = sizeof(float) * PW_TOTAL + sizeof(unsigned short
 // ---- workspace carve-up ---------------------------------------------------------------------------
 struct Workspace {
     ColLayout L;
-    int prec;          // 0: exact fp32 MFMA; 1: split-bf16 (bf16x3) main loops in qkv_kv / mlp0 / mlp3 (set from the call's flags)
+    int prec;          // 0: fp32 MFMA; 1: three-term split-bf16 (bf16x3), 2: six-term (bf16x6) main loops in qkv_kv / mlp0 / mlp3 (from the call's flags)
     int nt64;          // ld / 64 column tiles
     int nseg;          // 2*b
     int sc_nct, sc_nrt;   // score kernel tiles per frame (n2p/SC_BN, n1p/SC_BM)

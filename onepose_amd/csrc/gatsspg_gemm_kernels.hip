@@ -22,9 +22,10 @@ using QkvTileB = GemmTile<128, QKV_BN, 2, 2, false>;      // split-bf16 alternat
 // (forcing 80 VGPRs so that three 8-wave workgroups fit a CU -- the 756 tiles of the headline shape then fit 768 slots in one
 // round -- was measured: kernel -2 %, frames/s in flight unchanged; not kept)
 template <class T, int PREC = 0>
-__global__ __launch_bounds__(T::THREADS) void qkv_kv_kernel(const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
+__global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void qkv_kv_kernel(const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
                                                             const unsigned short* __restrict__ Whi,
                                                             const unsigned short* __restrict__ Wlo,
+                                                            const unsigned short* __restrict__ Wl2,
                                                             const float* __restrict__ Z, float* __restrict__ Qbuf,
                                                             float* __restrict__ kvpart, ColLayout L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -38,14 +39,18 @@ __global__ __launch_bounds__(T::THREADS) void qkv_kv_kernel(const float* __restr
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
     // this lane's 16 bias values per MFMA tile (rows 8k + 4 half + 0..3 of the tile: four 16-byte loads), requested BEFORE the
     // main loop.  (Read in the epilogue next to elu's branch they became 16 dependent load -> wait -> write rounds per lane.)
+    // (the six-term loop has no 16 registers to park it in and fetches it after the loop)
     float bias[T::TM][16];
+    auto load_bias = [&]() {
 #pragma unroll
-    for (int tm = 0; tm < T::TM; ++tm)
+        for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const vf4 b4 = ldg4(bqkv + rt * 128 + (wm * T::TM + tm) * 32 + 8 * k + 4 * half);
-            bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
-        }
+            for (int k = 0; k < 4; ++k) {
+                const vf4 b4 = ldg4(bqkv + rt * 128 + (wm * T::TM + tm) * 32 + 8 * k + 4 * half);
+                bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
+            }
+    };
+    if constexpr (PREC != 2) load_bias();
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     if constexpr (PREC == 1) {
@@ -54,11 +59,18 @@ __global__ __launch_bounds__(T::THREADS) void qkv_kv_kernel(const float* __restr
         gemm_mainloop_bf3<T>(
             acc, reinterpret_cast<unsigned short*>(smem), D / BK, [&](int kt) { return Ah + kt * BK; },
             [&](int kt) { return Al + kt * BK; }, D, [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
+    } else if constexpr (PREC == 2) {
+        const size_t ro = (size_t)rt * 128 * D;
+        gemm_mainloop_bf6<T>(
+            acc, reinterpret_cast<unsigned short*>(smem), D / BK,
+            [&](int kt, int pl) { return (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + kt * BK; }, D,
+            [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
     } else {
         gemm_mainloop<T>(
             acc, smem, D / BK, [&](int kt) { return A + kt * BK; }, D,
             [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
     }
+    if constexpr (PREC == 2) load_bias();
 
     if (rt < 2) {
 #pragma unroll
@@ -259,8 +271,9 @@ static constexpr unsigned long long* g_trace = nullptr;
 
 // ABL (profiling builds only, wrong results): main-loop ablations of gemm_mainloop_ex.  PREC as in qkv_kv_kernel.
 template <class T, int ABL = 0, int PREC = 0>
-__global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
+__global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                    const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
+                                                   const unsigned short* __restrict__ Wl2,
                                                    const float* __restrict__ Z, const float* __restrict__ MSG,
                                                    float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
                                                    unsigned long long* trace) {
@@ -276,14 +289,19 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
     const float* A = W0 + (size_t)rt * T::BM * 512;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
-    float bias[T::TM][16];   // requested before the main loop (see qkv_kv_kernel)
+    // requested before the main loop (see qkv_kv_kernel); the six-term loop has no 16 registers to park it in (128-VGPR budget of
+    // two 8-wave workgroups per CU) and fetches it after the loop
+    float bias[T::TM][16];
+    auto load_bias = [&]() {
 #pragma unroll
-    for (int tm = 0; tm < T::TM; ++tm)
+        for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const vf4 b4 = ldg4(b0 + rt * T::BM + (wm * T::TM + tm) * 32 + 8 * k + 4 * half);
-            bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
-        }
+            for (int k = 0; k < 4; ++k) {
+                const vf4 b4 = ldg4(b0 + rt * T::BM + (wm * T::TM + tm) * 32 + 8 * k + 4 * half);
+                bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
+            }
+    };
+    if constexpr (PREC != 2) load_bias();
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     // ABL == 5 (profiling): every workgroup streams the SAME weight panel and the SAME column tile (cache-hot operands)
@@ -297,9 +315,15 @@ __global__ __launch_bounds__(T::THREADS) void mlp0_kernel(const float* __restric
         gemm_mainloop_bf3<T>(
             acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, [&](int kt) { return Bh + kt * BK; },
             [&](int kt) { return Bl + kt * BK; }, 512, bl, ld);
+    } else if constexpr (PREC == 2) {
+        const size_t ro = (size_t)rt * T::BM * 512;
+        gemm_mainloop_bf6<T>(
+            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK,
+            [&](int kt, int pl) { return (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + kt * BK; }, 512, bl, ld);
     } else {
         gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL)>(acc, smem, 512 / BK, al, 512, bl, ld);
     }
+    if constexpr (PREC == 2) load_bias();
     const unsigned long long t_loop = trace ? wall_clock64() : 0;
     const TileSeg ts = tile_seg(L, c0, T::BN);
     constexpr int TS = T::BN + 1;
@@ -429,8 +453,9 @@ using Mlp3TileTallW8 = GemmTile<128, 64, 4, 2, false>;   // both arithmetics: 12
 using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;          // alternative (tuning builds): 64x64 on 4 waves, 504 workgroups
 
 template <class T, int ABL = 0, int PREC = 0>
-__global__ __launch_bounds__(T::THREADS) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
+__global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
                                                    const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
+                                                   const unsigned short* __restrict__ Wl2,
                                                    const float* __restrict__ U, const float* __restrict__ stats,
                                                    float* __restrict__ Z, ColLayout L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -472,6 +497,12 @@ __global__ __launch_bounds__(T::THREADS) void mlp3_kernel(const float* __restric
         auto bx1 = [](float v, float2 ms) { return fmaxf((v - ms.x) * ms.y, 0.f); };
         gemm_mainloop_bf3_ex<T, decltype(ah), decltype(alo), decltype(bl), decltype(xm), decltype(xr), decltype(bx1), true>(
             acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, ah, alo, 512, bl, ld, xm, xr, bx1);
+    } else if constexpr (PREC == 2) {
+        const size_t ro = (size_t)rt * T::BM * 512;
+        auto ap = [&](int kt, int pl) { return (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + kt * BK; };
+        auto bx1 = [](float v, float2 ms) { return fmaxf((v - ms.x) * ms.y, 0.f); };
+        gemm_mainloop_bf6_ex<T, decltype(ap), decltype(bl), decltype(xm), decltype(xr), decltype(bx1), true>(
+            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, ap, 512, bl, ld, xm, xr, bx1);
     } else {
         auto bx = [](vf4& v, float2 ms) {
 #pragma unroll
@@ -688,14 +719,17 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     unsigned short* dst = packedb + (size_t)layer * AttnWB::SIZE;
     constexpr size_t NQ = 768 * 256, N0 = 512 * 512, N3 = 256 * 512;
     float x;
-    size_t hi, lo;
-    if (e < NQ) { x = src[AttnW::WQKV + e]; hi = AttnWB::QKV_HI + e; lo = AttnWB::QKV_LO + e; }
-    else if (e < NQ + N0) { x = src[AttnW::W0 + (e - NQ)]; hi = AttnWB::W0_HI + (e - NQ); lo = AttnWB::W0_LO + (e - NQ); }
-    else if (e < NQ + N0 + N3) { x = src[AttnW::W3 + (e - NQ - N0)]; hi = AttnWB::W3_HI + (e - NQ - N0); lo = AttnWB::W3_LO + (e - NQ - N0); }
+    size_t hi, lo, lo2;
+    if (e < NQ) { x = src[AttnW::WQKV + e]; hi = AttnWB::QKV_HI + e; lo = AttnWB::QKV_LO + e; lo2 = AttnWB::QKV_LO2 + e; }
+    else if (e < NQ + N0) { x = src[AttnW::W0 + (e - NQ)]; hi = AttnWB::W0_HI + (e - NQ); lo = AttnWB::W0_LO + (e - NQ); lo2 = AttnWB::W0_LO2 + (e - NQ); }
+    else if (e < NQ + N0 + N3) { x = src[AttnW::W3 + (e - NQ - N0)]; hi = AttnWB::W3_HI + (e - NQ - N0); lo = AttnWB::W3_LO + (e - NQ - N0); lo2 = AttnWB::W3_LO2 + (e - NQ - N0); }
     else return;
     const unsigned h = bf16_rne_bits(x);
+    const float r1 = x - __uint_as_float(h << 16);
+    const unsigned m = bf16_rne_bits(r1);
     dst[hi] = (unsigned short)h;
-    dst[lo] = (unsigned short)bf16_rne_bits(x - __uint_as_float(h << 16));
+    dst[lo] = (unsigned short)m;
+    dst[lo2] = (unsigned short)bf16_rne_bits(r1 - __uint_as_float(m << 16));
 }
 
 void launch_split_weights(const float* packed, unsigned short* packedb, hipStream_t s) {
@@ -711,6 +745,9 @@ constexpr size_t smem_bytes() {
     size_t b = sizeof(float) * T::SMEM_FLOATS;
     if constexpr (PREC == 1) {
         if (Bf3Layout<T>::SMEM_BYTES > b) b = Bf3Layout<T>::SMEM_BYTES;
+    }
+    if constexpr (PREC == 2) {
+        if (Bf6Layout<T>::SMEM_BYTES > b) b = Bf6Layout<T>::SMEM_BYTES;
     }
     return b;
 }
@@ -736,7 +773,8 @@ static void launch_qkv_t(const float* Wqkv, const float* bqkv, const unsigned sh
     const int NT = active_tiles(w.L);
     allow_big_lds<qkv_kv_kernel<T, PREC>>();
     GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_kernel<T, PREC>), dim3(xcd_grid(6, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>()), s,
-                   Wqkv, bqkv, wb ? wb + AttnWB::QKV_HI : nullptr, wb ? wb + AttnWB::QKV_LO : nullptr, w.Z, w.Q, w.kvpart, w.L);
+                   Wqkv, bqkv, wb ? wb + AttnWB::QKV_HI : nullptr, wb ? wb + AttnWB::QKV_LO : nullptr, wb ? wb + AttnWB::QKV_LO2 : nullptr, w.Z,
+                   w.Q, w.kvpart, w.L);
 }
 
 void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s,
@@ -744,6 +782,7 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* w
     static const int tq = tuning_knob("QKV_BTILE", 0);   // tuning builds: 1 = split-bf16 on the 4-wave tile
     if (w.prec == 1 && tq == 1) launch_qkv_t<QkvTileB, 1>(Wqkv, bqkv, wb, w, s, hk);
     else if (w.prec == 1) launch_qkv_t<QkvTileW8, 1>(Wqkv, bqkv, wb, w, s, hk);
+    else if (w.prec == 2) launch_qkv_t<QkvTileW8, 2>(Wqkv, bqkv, wb, w, s, hk);
     else launch_qkv_t<QkvTileW8, 0>(Wqkv, bqkv, wb, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3((KVP4 + 63) / 64, w.nseg * H), dim3(1024), 0, s, w.kvpart,
                    w.kvfin, w.L);
@@ -760,7 +799,8 @@ static void launch_mlp0_t(const float* W0, const float* b0, const unsigned short
     allow_big_lds<mlp0_kernel<T, ABL, PREC>>();
     const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
     GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_kernel<T, ABL, PREC>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
-                   (smem_bytes<T, PREC>()), s, W0, b0, wb ? wb + AttnWB::W0_HI : nullptr, wb ? wb + AttnWB::W0_LO : nullptr, w.Z,
+                   (smem_bytes<T, PREC>()), s, W0, b0, wb ? wb + AttnWB::W0_HI : nullptr, wb ? wb + AttnWB::W0_LO : nullptr,
+                   wb ? wb + AttnWB::W0_LO2 : nullptr, w.Z,
                    w.MSG, w.U, w.statpart, w.L, g_trace);
 }
 template <class T, int ABL, int PREC>
@@ -769,7 +809,8 @@ static void launch_mlp3_t(const float* W3, const float* b3, const unsigned short
     allow_big_lds<mlp3_kernel<T, ABL, PREC>>();
     const int NT = active_tiles(w.L) / (T::BN / 64);
     GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_kernel<T, ABL, PREC>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS),
-                   (smem_bytes<T, PREC>()), s, W3, b3, wb ? wb + AttnWB::W3_HI : nullptr, wb ? wb + AttnWB::W3_LO : nullptr, w.U,
+                   (smem_bytes<T, PREC>()), s, W3, b3, wb ? wb + AttnWB::W3_HI : nullptr, wb ? wb + AttnWB::W3_LO : nullptr,
+                   wb ? wb + AttnWB::W3_LO2 : nullptr, w.U,
                    w.stats, w.Z, w.L);
 }
 
@@ -782,6 +823,8 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     if (w.prec == 1) {
         if (tb0 == 1) launch_mlp0_t<Mlp0TileB8, 0, 1>(W0, b0, wb, w, s, hk);
         else launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, wb, w, s, hk);
+    } else if (w.prec == 2) {
+        launch_mlp0_t<Mlp0TileW8, 0, 2>(W0, b0, wb, w, s, hk);
     }
 #ifdef GATSSPG_PROFILING_BUILD
     else if (t0 == 11) launch_mlp0_t<Mlp0TileW8, 1, 0>(W0, b0, wb, w, s, hk);   // no global loads in the loop
@@ -794,6 +837,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
     if (w.prec == 1 && t3 == 0) launch_mlp3_t<Mlp3Tile, 0, 1>(W3, b3, wb, w, s, hk);
     else if (w.prec == 1) launch_mlp3_t<Mlp3TileTallW8, 0, 1>(W3, b3, wb, w, s, hk);
+    else if (w.prec == 2) launch_mlp3_t<Mlp3TileTallW8, 0, 2>(W3, b3, wb, w, s, hk);
 #ifdef GATSSPG_PROFILING_BUILD
     else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3, 0>(W3, b3, wb, w, s, hk);   // steady-state loop cut: fixed cost only
 #endif

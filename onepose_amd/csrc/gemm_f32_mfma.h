@@ -427,6 +427,186 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
     }
 }
 
+// =====================================================================================================
+// Six-term split-bf16 ("bf16x6"): x = x1 + x2 + x3 EXACTLY (three bf16 planes hold the 24 mantissa bits of an fp32 value),
+// product = a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1; the dropped terms (a2b3, a3b2, a3b3) are <= 2^-24 |ab| -- the size of
+// ONE fp32 rounding of the product -- and the sum is accumulated in fp32 by the MFMA exactly like the f32 path does.
+// 6 x 32 cycles per 32x32x16 block against 8 x 64 for v_mfma_f32_32x32x2_f32.
+// LDS images: three planes per operand, rows of 32 bf16 (64 bytes, NO pad: with the 40-element rows of the three-term loop
+// two stages of six planes would not leave room for two workgroups per CU); the 16-byte chunk c of row r is stored at chunk
+// c ^ ((r >> 2) & 3), so the fragment reads of 16 consecutive rows still cover the 16 four-bank groups once.
+// =====================================================================================================
+__device__ __forceinline__ void bf16_split3(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xFFFF0000u);
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){ra, rb}, bf16x2));
+    const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xFFFF0000u);
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){sa, sb}, bf16x2));
+}
+
+template <class T>
+struct Bf6Layout {
+    static constexpr int KS = 32;                                       // bf16 per LDS row (swizzled, no pad)
+    static constexpr int A_PLANE = T::BM * KS, B_PLANE = T::BN * KS;    // in bf16 elements
+    static constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;
+    static constexpr size_t SMEM_BYTES = 2 * (size_t)STAGE * 2;         // two stages
+    static constexpr int A_PIECES = T::BM * 4 * 3 / T::THREADS;         // 16-byte pieces per thread per slab (three planes)
+    static constexpr int KPT = BK * T::BN / T::THREADS;                 // consecutive k rows per thread (one B column)
+    static_assert(KPT == 4 || KPT == 8, "a thread owns 4 or 8 consecutive k of one column");
+    static_assert(A_PIECES >= 1 && ((T::BM * 4) % T::THREADS == 0 || T::THREADS % (T::BM * 4) == 0), "A plane of a piece is static");
+    static_assert(T::BN % 64 == 0, "a wave covers 64 consecutive columns of one k group");
+};
+__device__ __forceinline__ int bf6_swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+
+// a_pl(kt, plane): bf16 plane pointer of A slab kt (&A_plane[row0][kt*32], row stride lda elements); the rest as in
+// gemm_mainloop_bf3_ex.
+template <class T, class APlane, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX>
+__device__ __forceinline__ void gemm_mainloop_bf6_ex(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, APlane a_pl, int lda,
+                                                     BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform) {
+    static_assert(!T::AKM && !T::BU, "row-major A, aligned B");
+    using LY = Bf6Layout<T>;
+    constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN, KS = LY::KS, AP = LY::A_PIECES, KPT = LY::KPT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    unsigned a_goff[AP];
+    int a_soff[AP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        const int idx = p * T::THREADS + tid;
+        const int rem = idx % (BM * 4), r = rem >> 2, c8 = rem & 3;
+        a_goff[p] = 2u * (unsigned)(r * lda + c8 * 8);
+        a_soff[p] = r * KS + bf6_swz(r, c8) * 8;
+    }
+    const int bcol = tid % BN;
+    const int k0 = __builtin_amdgcn_readfirstlane(tid / BN) * KPT;
+    unsigned b_goff[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) b_goff[j] = 4u * (unsigned)((k0 + j) * ldb + bcol);
+    const int b_soff = bcol * KS + bf6_swz(bcol, k0 >> 3) * 8 + (k0 & 7);
+
+    u32x4 ra0[AP], ra1[AP];
+    float rb0[KPT], rb1[KPT];
+    float2 rx0[KPT], rx1[KPT];
+    auto gload = [&](int kt, u32x4(&ra)[AP], float(&rb)[KPT], float2(&rx)[KPT]) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            const int plane = (p * T::THREADS) / (BM * 4);
+            ra[p] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a_pl(kt, plane)) + a_goff[p]);
+        }
+        const float* bb = b_slab(kt);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            rb[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(bb) + b_goff[j]);
+            if constexpr (HAS_AUX) rx[j] = make_float2(x_mean(kt)[k0 + j], x_rstd(kt)[k0 + j]);
+        }
+    };
+    auto swrite = [&](unsigned short* stage, const u32x4(&ra)[AP], const float(&rb)[KPT], const float2(&rx)[KPT]) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            const int plane = (p * T::THREADS) / (BM * 4);
+            *reinterpret_cast<u32x4*>(stage + plane * LY::A_PLANE + a_soff[p]) = ra[p];
+        }
+        unsigned short* B0 = stage + 3 * LY::A_PLANE;
+        unsigned q0[KPT / 2], q1[KPT / 2], q2[KPT / 2];
+#pragma unroll
+        for (int j = 0; j < KPT; j += 2) {
+            float v0 = rb[j], v1 = rb[j + 1];
+            if constexpr (HAS_AUX) {
+                v0 = bxform(v0, rx[j]);
+                v1 = bxform(v1, rx[j + 1]);
+            }
+            bf16_split3(v0, v1, q0[j / 2], q1[j / 2], q2[j / 2]);
+        }
+        if constexpr (KPT == 8) {
+            *reinterpret_cast<u32x4*>(B0 + b_soff) = (u32x4){q0[0], q0[1], q0[2], q0[3]};
+            *reinterpret_cast<u32x4*>(B0 + LY::B_PLANE + b_soff) = (u32x4){q1[0], q1[1], q1[2], q1[3]};
+            *reinterpret_cast<u32x4*>(B0 + 2 * LY::B_PLANE + b_soff) = (u32x4){q2[0], q2[1], q2[2], q2[3]};
+        } else {
+            *reinterpret_cast<u32x2*>(B0 + b_soff) = (u32x2){q0[0], q0[1]};
+            *reinterpret_cast<u32x2*>(B0 + LY::B_PLANE + b_soff) = (u32x2){q1[0], q1[1]};
+            *reinterpret_cast<u32x2*>(B0 + 2 * LY::B_PLANE + b_soff) = (u32x2){q2[0], q2[1]};
+        }
+    };
+    auto gload_a = [&](int kt, u32x4(&ra)[AP]) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            const int plane = (p * T::THREADS) / (BM * 4);
+            ra[p] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a_pl(kt, plane)) + a_goff[p]);
+        }
+    };
+    auto gload_b = [&](int kt, float(&rb)[KPT], float2(&rx)[KPT]) {
+        const float* bb = b_slab(kt);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            rb[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(bb) + b_goff[j]);
+            if constexpr (HAS_AUX) rx[j] = make_float2(x_mean(kt)[k0 + j], x_rstd(kt)[k0 + j]);
+        }
+    };
+    // fragments of one k16 step: k = 16 s + 8 half .. + 7, the same k assignment for A and B
+    auto read_frags = [&](const unsigned short* stage, int s, bf16x8 (&af)[3][TM], bf16x8 (&bf)[3][TN]) {
+        const unsigned short* Ap = stage;
+        const unsigned short* Bp = stage + 3 * LY::A_PLANE;
+        const int chunk = 2 * s + half;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int row = (wm * TM + tm) * 32 + l31;
+            const int off = row * KS + bf6_swz(row, chunk) * 8;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[pl][tm] = *reinterpret_cast<const bf16x8*>(Ap + pl * LY::A_PLANE + off);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = (wn * TN + tn) * 32 + l31;
+            const int off = col * KS + bf6_swz(col, chunk) * 8;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bf[pl][tn] = *reinterpret_cast<const bf16x8*>(Bp + pl * LY::B_PLANE + off);
+        }
+    };
+    // term pair g of one k16 step, small terms first: (a3 b1, a1 b3), (a2 b2, a2 b1), (a1 b2, a1 b1)
+    auto mfma_pair = [&](const bf16x8 (&af)[3][TM], const bf16x8 (&bf)[3][TN], int g) {
+        const int pa0 = g == 0 ? 2 : g == 1 ? 1 : 0, pb0 = g == 0 ? 0 : 1;
+        const int pa1 = g == 0 ? 0 : g == 1 ? 1 : 0, pb1 = g == 0 ? 2 : 0;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa0][tm], bf[pb0][tn], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa1][tm], bf[pb1][tn], acc[tm][tn], 0, 0, 0);
+            }
+    };
+    // One step = one read phase (all twelve fragments), twelve MFMAs, then the split + LDS write of slab i+1 and the global loads
+    // of slab i+3.  (Placing the second-step reads, the LDS writes and the loads BETWEEN the MFMA pairs, as the fp32 loop does,
+    // was measured on this loop: mlp0 34.9 vs 32.5 us, 1337 vs 1435 frames/s -- the bf16 MFMAs are too short to hide them.)
+    auto step = [&](const unsigned short* cur, unsigned short* nxt, int kt_load, u32x4(&ra)[AP], float(&rb)[KPT], float2(&rx)[KPT]) {
+        bf16x8 af0[3][TM], bf0[3][TN], af1[3][TM], bf1[3][TN];
+        read_frags(cur, 0, af0, bf0);
+        read_frags(cur, 1, af1, bf1);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) mfma_pair(af0, bf0, g);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) mfma_pair(af1, bf1, g);
+        swrite(nxt, ra, rb, rx);
+        asm volatile("" ::: "memory");
+        gload_a(kt_load, ra);
+        gload_b(kt_load, rb, rx);
+    };
+    unsigned short* buf0 = smem;
+    unsigned short* buf1 = smem + LY::STAGE;
+    const int last = KT - 1;
+    gload(0, ra1, rb1, rx1);
+    gload(min(1, last), ra0, rb0, rx0);
+    swrite(buf0, ra1, rb1, rx1);
+    gload(min(2, last), ra1, rb1, rx1);
+    __syncthreads();
+    for (int i = 0; i < KT; i += 2) {
+        step(buf0, buf1, min(i + 3, last), ra0, rb0, rx0);
+        __syncthreads();
+        step(buf1, buf0, min(i + 4, last), ra1, rb1, rx1);
+        __syncthreads();
+    }
+}
+
 struct NoXform1 {
     __device__ __forceinline__ float operator()(float v, float2) const { return v; }
 };
@@ -436,6 +616,14 @@ __device__ __forceinline__ void gemm_mainloop_bf3(f32x16 (&acc)[T::TM][T::TN], u
     auto nox = [](int) { return static_cast<const float*>(nullptr); };
     gemm_mainloop_bf3_ex<T, AHi, ALo, BSlab, decltype(nox), decltype(nox), NoXform1, false>(acc, smem, KT, a_hi, a_lo, lda, b_slab,
                                                                                           ldb, nox, nox, NoXform1());
+}
+
+template <class T, class APlane, class BSlab>
+__device__ __forceinline__ void gemm_mainloop_bf6(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, APlane a_pl, int lda,
+                                                  BSlab b_slab, int ldb) {
+    auto nox = [](int) { return static_cast<const float*>(nullptr); };
+    gemm_mainloop_bf6_ex<T, APlane, BSlab, decltype(nox), decltype(nox), NoXform1, false>(acc, smem, KT, a_pl, lda, b_slab, ldb, nox,
+                                                                                        nox, NoXform1());
 }
 
 // convenience wrapper without per-row aux / transform

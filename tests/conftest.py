@@ -47,8 +47,9 @@ def bench_golden_meta():
 # golden).  bf16x3: each operand carries 2 x 8 mantissa bits, i.e. ~4e-6 relative per product instead of 6e-8; after 24
 # GEMMs, the 1/0.07 score scaling and the exp this reaches a few 1e-4 RELATIVE on conf entries (absolute error stays
 # < 5e-8 on the random-weight fixtures, where conf ~ 1e-4).  Measured on head_b8: 1-2 flips in 64000 arg-maxes, at
-# reference gaps of 4e-5 .. 3.4e-4; its documented tie gap is 1e-3.
-TIE_GAP = {"fp32": 2e-5, "bf16x3": 1e-3}
+# reference gaps of 4e-5 .. 3.4e-4; its documented tie gap is 1e-3.  bf16x6: operands split exactly into 3 x 8 mantissa bits,
+# six of the nine term products kept (dropped: <= 2^-24 |ab|) -- fp32-class, held to the fp32 tolerance.
+TIE_GAP = {"fp32": 2e-5, "bf16x3": 1e-3, "bf16x6": 2e-5}
 
 
 def argmax_flips(idx, ref_idx, ref_gap, what, tie_gap=TIE_GAP["fp32"]):

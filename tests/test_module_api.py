@@ -95,6 +95,8 @@ def test_precision_is_a_constructor_argument_not_an_environment_variable(monkeyp
     assert m.precision == "fp32" and m.engine.flags() == _native.FLAG_INCLUDE_SELF
     b = GATsSuperGlue(HP, precision="bf16x3")
     assert b.engine.flags() == _native.FLAG_INCLUDE_SELF | _native.FLAG_PREC_BF16X3
+    b.precision = "bf16x6"
+    assert b.engine.flags() == _native.FLAG_INCLUDE_SELF | _native.FLAG_PREC_BF16X6
     b.precision = "fp32"
     assert b.engine.flags() == _native.FLAG_INCLUDE_SELF
     with pytest.raises(ValueError, match="precision must be one of"):
