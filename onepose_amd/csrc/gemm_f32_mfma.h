@@ -577,7 +577,8 @@ __device__ __forceinline__ void gemm_mainloop_bf6_ex(f32x16 (&acc)[T::TM][T::TN]
     };
     // One step = one read phase (all twelve fragments), twelve MFMAs, then the split + LDS write of slab i+1 and the global loads
     // of slab i+3.  (Placing the second-step reads, the LDS writes and the loads BETWEEN the MFMA pairs, as the fp32 loop does,
-    // was measured on this loop: mlp0 34.9 vs 32.5 us, 1337 vs 1435 frames/s -- the bf16 MFMAs are too short to hide them.)
+    // was measured on this loop: mlp0 34.9 vs 32.5 us, 1337 vs 1435 frames/s -- the bf16 MFMAs are too short to hide them;
+    // write + loads BEFORE the MFMAs: 1137 frames/s -- the write then waits for loads that have had one step, not two, to land.)
     auto step = [&](const unsigned short* cur, unsigned short* nxt, int kt_load, u32x4(&ra)[AP], float(&rb)[KPT], float2(&rx)[KPT]) {
         bf16x8 af0[3][TM], bf0[3][TN], af1[3][TM], bf1[3][TN];
         read_frags(cur, 0, af0, bf0);
