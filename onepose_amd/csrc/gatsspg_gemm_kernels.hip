@@ -824,7 +824,8 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
         if (tb0 == 1) launch_mlp0_t<Mlp0TileB8, 0, 1>(W0, b0, wb, w, s, hk);
         else launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, wb, w, s, hk);
     } else if (w.prec == 2) {
-        launch_mlp0_t<Mlp0TileW8, 0, 2>(W0, b0, wb, w, s, hk);
+        if (tb0 == 1) launch_mlp0_t<Mlp0TileB8, 0, 2>(W0, b0, wb, w, s, hk);
+        else launch_mlp0_t<Mlp0TileW8, 0, 2>(W0, b0, wb, w, s, hk);
     }
 #ifdef GATSSPG_PROFILING_BUILD
     else if (t0 == 11) launch_mlp0_t<Mlp0TileW8, 1, 0>(W0, b0, wb, w, s, hk);   // no global loads in the loop
