@@ -97,7 +97,7 @@ constexpr size_t PW_TOTAL = PW_FINAL_B + 256;   // floats
 
 // Split-bf16 planes of the three big GEMM operators (GATSSPG_FLAG_PREC_BF16X3 / _BF16X6): appended to the fp32 blob, in bf16
 // elements from (unsigned short*)(packed + PW_TOTAL).  w = hi + lo with hi = RNE_bf16(w), lo = RNE_bf16(w - hi);
-// same row order as the fp32 matrices they are split from.
+// rows in the order of the fp32 matrices they are split from, elements slab-major: (m, k) at ((k / 32) * M + m) * 32 + k % 32.
 struct AttnWB {
     static constexpr size_t QKV_HI = 0;                          // [768][256]
     static constexpr size_t QKV_LO = QKV_HI + 768 * 256;

@@ -54,16 +54,16 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void qkv_kv_kernel
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     if constexpr (PREC == 1) {
-        const unsigned short* Ah = Whi + (size_t)rt * 128 * D;
-        const unsigned short* Al = Wlo + (size_t)rt * 128 * D;
+        // weight planes are slab-major ([K/32][rows][32], split_weights_kernel): a 128 x 32 slab is 8 KB of consecutive bytes
+        const size_t ro = (size_t)rt * 128 * BK;
         gemm_mainloop_bf3<T>(
-            acc, reinterpret_cast<unsigned short*>(smem), D / BK, [&](int kt) { return Ah + kt * BK; },
-            [&](int kt) { return Al + kt * BK; }, D, [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
+            acc, reinterpret_cast<unsigned short*>(smem), D / BK, [&](int kt) { return Whi + ro + (size_t)kt * 768 * BK; },
+            [&](int kt) { return Wlo + ro + (size_t)kt * 768 * BK; }, BK, [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
     } else if constexpr (PREC == 2) {
-        const size_t ro = (size_t)rt * 128 * D;
+        const size_t ro = (size_t)rt * 128 * BK;
         gemm_mainloop_bf6<T>(
             acc, reinterpret_cast<unsigned short*>(smem), D / BK,
-            [&](int kt, int pl) { return (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + kt * BK; }, D,
+            [&](int kt, int pl) { return (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + (size_t)kt * 768 * BK; }, BK,
             [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
     } else {
         gemm_mainloop<T>(
@@ -310,16 +310,15 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp0_kernel(c
     auto al = [&](int kt) { return Ah + kt * BK; };
     auto bl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : MSG + (size_t)(kt - 8) * BK * ld) + ch0; };
     if constexpr (PREC == 1) {
-        const unsigned short* Bh = Whi + (size_t)rt * T::BM * 512;
-        const unsigned short* Bl = Wlo + (size_t)rt * T::BM * 512;
+        const size_t ro = (size_t)rt * T::BM * BK;   // slab-major planes (see qkv_kv_kernel)
         gemm_mainloop_bf3<T>(
-            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, [&](int kt) { return Bh + kt * BK; },
-            [&](int kt) { return Bl + kt * BK; }, 512, bl, ld);
+            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, [&](int kt) { return Whi + ro + (size_t)kt * 512 * BK; },
+            [&](int kt) { return Wlo + ro + (size_t)kt * 512 * BK; }, BK, bl, ld);
     } else if constexpr (PREC == 2) {
-        const size_t ro = (size_t)rt * T::BM * 512;
+        const size_t ro = (size_t)rt * T::BM * BK;
         gemm_mainloop_bf6<T>(
             acc, reinterpret_cast<unsigned short*>(smem), 512 / BK,
-            [&](int kt, int pl) { return (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + kt * BK; }, 512, bl, ld);
+            [&](int kt, int pl) { return (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + (size_t)kt * 512 * BK; }, BK, bl, ld);
     } else {
         gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL)>(acc, smem, 512 / BK, al, 512, bl, ld);
     }
@@ -490,19 +489,18 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp3_kernel(c
     auto xm = [&](int kt) { return mean + kt * BK; };
     auto xr = [&](int kt) { return rstd + kt * BK; };
     if constexpr (PREC == 1) {
-        const unsigned short* Bh = Whi + (size_t)rt * T::BM * 512;
-        const unsigned short* Bl = Wlo + (size_t)rt * T::BM * 512;
-        auto ah = [&](int kt) { return Bh + kt * BK; };
-        auto alo = [&](int kt) { return Bl + kt * BK; };
+        const size_t ro = (size_t)rt * T::BM * BK;   // slab-major planes (see qkv_kv_kernel)
+        auto ah = [&](int kt) { return Whi + ro + (size_t)kt * 256 * BK; };
+        auto alo = [&](int kt) { return Wlo + ro + (size_t)kt * 256 * BK; };
         auto bx1 = [](float v, float2 ms) { return fmaxf((v - ms.x) * ms.y, 0.f); };
         gemm_mainloop_bf3_ex<T, decltype(ah), decltype(alo), decltype(bl), decltype(xm), decltype(xr), decltype(bx1), true>(
-            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, ah, alo, 512, bl, ld, xm, xr, bx1);
+            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, ah, alo, BK, bl, ld, xm, xr, bx1);
     } else if constexpr (PREC == 2) {
-        const size_t ro = (size_t)rt * T::BM * 512;
-        auto ap = [&](int kt, int pl) { return (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + kt * BK; };
+        const size_t ro = (size_t)rt * T::BM * BK;
+        auto ap = [&](int kt, int pl) { return (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + (size_t)kt * 256 * BK; };
         auto bx1 = [](float v, float2 ms) { return fmaxf((v - ms.x) * ms.y, 0.f); };
         gemm_mainloop_bf6_ex<T, decltype(ap), decltype(bl), decltype(xm), decltype(xr), decltype(bx1), true>(
-            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, ap, 512, bl, ld, xm, xr, bx1);
+            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, ap, BK, bl, ld, xm, xr, bx1);
     } else {
         auto bx = [](vf4& v, float2 ms) {
 #pragma unroll
@@ -718,11 +716,15 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     const float* src = packed + PW_ATTN + (size_t)layer * AttnW::SIZE;
     unsigned short* dst = packedb + (size_t)layer * AttnWB::SIZE;
     constexpr size_t NQ = 768 * 256, N0 = 512 * 512, N3 = 256 * 512;
+    // planes are stored SLAB-MAJOR: element (m, k) of an [M][K] operator at ((k / 32) * M + m) * 32 + k % 32, so that the
+    // 128-row x 32-k slab a workgroup stages per step is 8 KB of consecutive bytes (full 128-byte lines per load instruction
+    // instead of 64-byte row pieces 2 * K bytes apart)
     float x;
-    size_t hi, lo, lo2;
-    if (e < NQ) { x = src[AttnW::WQKV + e]; hi = AttnWB::QKV_HI + e; lo = AttnWB::QKV_LO + e; lo2 = AttnWB::QKV_LO2 + e; }
-    else if (e < NQ + N0) { x = src[AttnW::W0 + (e - NQ)]; hi = AttnWB::W0_HI + (e - NQ); lo = AttnWB::W0_LO + (e - NQ); lo2 = AttnWB::W0_LO2 + (e - NQ); }
-    else if (e < NQ + N0 + N3) { x = src[AttnW::W3 + (e - NQ - N0)]; hi = AttnWB::W3_HI + (e - NQ - N0); lo = AttnWB::W3_LO + (e - NQ - N0); lo2 = AttnWB::W3_LO2 + (e - NQ - N0); }
+    size_t hi, lo, lo2, d;
+    auto slab_major = [](size_t i, size_t M, size_t K) { const size_t m = i / K, k = i % K; return ((k >> 5) * M + m) * 32 + (k & 31); };
+    if (e < NQ) { x = src[AttnW::WQKV + e]; d = slab_major(e, 768, 256); hi = AttnWB::QKV_HI + d; lo = AttnWB::QKV_LO + d; lo2 = AttnWB::QKV_LO2 + d; }
+    else if (e < NQ + N0) { x = src[AttnW::W0 + (e - NQ)]; d = slab_major(e - NQ, 512, 512); hi = AttnWB::W0_HI + d; lo = AttnWB::W0_LO + d; lo2 = AttnWB::W0_LO2 + d; }
+    else if (e < NQ + N0 + N3) { x = src[AttnW::W3 + (e - NQ - N0)]; d = slab_major(e - NQ - N0, 256, 512); hi = AttnWB::W3_HI + d; lo = AttnWB::W3_LO + d; lo2 = AttnWB::W3_LO2 + d; }
     else return;
     const unsigned h = bf16_rne_bits(x);
     const float r1 = x - __uint_as_float(h << 16);
