@@ -11,6 +11,7 @@ Lightning container classes that are not importable here).
 from __future__ import annotations
 
 import pickle
+from collections.abc import Mapping, Sequence
 
 import torch
 import torch.nn as nn
@@ -69,16 +70,18 @@ def _plain(x):
         if isinstance(inner, (list, tuple)):         # omegaconf ListConfig
             return [_plain(v) for v in inner]
         return {k: _plain(v) for k, v in x.items()}
-    if isinstance(x, dict):
+    if isinstance(x, Mapping):        # dict, and real omegaconf.DictConfig / Lightning AttributeDict when those are installed
         return {k: _plain(v) for k, v in x.items()}
-    if isinstance(x, (list, tuple)):
+    if isinstance(x, Sequence) and not isinstance(x, (str, bytes)):   # list / tuple / omegaconf.ListConfig
         return [_plain(v) for v in x]
     return x
 
 
-def read_checkpoint(path, map_location="cpu"):
+def read_checkpoint(path, map_location="cpu", overrides=None):
     """-> (matcher_state_dict, hparams).  ``matcher.`` prefix stripped; hparams fall back to the shipped
-    config for any key the (possibly stubbed) ``hyper_parameters`` entry does not yield."""
+    config for any key the (possibly stubbed) ``hyper_parameters`` entry does not yield.  Keys of ``overrides`` are
+    taken from there and NOT decoded from the file (the way out when a stored value cannot be decoded)."""
+    overrides = dict(overrides or {})
     try:
         ckpt = torch.load(path, map_location=map_location, weights_only=False)
     except Exception:  # noqa: BLE001 -- classes of missing packages inside the pickle
@@ -91,12 +94,13 @@ def read_checkpoint(path, map_location="cpu"):
     raw = _plain(ckpt.get("hyper_parameters", {})) if isinstance(ckpt, dict) else {}
     if isinstance(raw, dict):
         for k in DEFAULT_HPARAMS:
-            if k not in raw:
+            if k not in raw or k in overrides:
                 continue
             if isinstance(raw[k], dict):   # a container that could not be decoded: never fall back silently
                 raise ValueError(f"checkpoint hyper-parameter '{k}' could not be decoded ({type(raw[k]).__name__} with keys "
                                  f"{sorted(raw[k])[:6]}); pass it explicitly: load_from_checkpoint(path, {k}=...)")
             hp[k] = raw[k]
+    hp.update({k: v for k, v in overrides.items() if k in DEFAULT_HPARAMS})
     return matcher, hp
 
 
@@ -114,8 +118,7 @@ class LitModelGATsSPG(nn.Module):
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, map_location="cpu", **overrides):
-        sd, hp = read_checkpoint(checkpoint_path, map_location)
-        hp.update({k: v for k, v in overrides.items() if k in DEFAULT_HPARAMS})
+        sd, hp = read_checkpoint(checkpoint_path, map_location, overrides)
         model = cls(**hp)
         model.matcher.load_state_dict(sd, strict=True)
         return model

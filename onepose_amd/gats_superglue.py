@@ -142,6 +142,10 @@ class Database:
     def __init__(self, cache, desc3d_db, desc2d_db, b, n2, num_leaf, weights_key):
         self.cache, self.desc3d_db, self.desc2d_db = cache, desc3d_db, desc2d_db
         self.b, self.n2, self.num_leaf, self.weights_key = b, n2, num_leaf, weights_key
+        # the cache is written on the stream prepare_database ran on; other streams wait on this event before reading it
+        self.stream = torch.cuda.current_stream(cache.device).cuda_stream
+        self.ready = torch.cuda.Event()
+        self.ready.record(torch.cuda.current_stream(cache.device))
 
     def check(self, engine, b, n2, num_leaf, device):
         if (b, n2, num_leaf) != (self.b, self.n2, self.num_leaf) or self.cache.device != device:
@@ -150,6 +154,9 @@ class Database:
         engine.packed_weights(device)
         if (engine._packed_key, engine.flags()) != self.weights_key:
             raise ValueError("database cache was built with different weights / flags / precision; call prepare_database again")
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream != self.stream:
+            cur.wait_event(self.ready)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -182,7 +189,10 @@ class GATsSPGEngine:
     """Owns the device-side packed weights and workspaces of one module on one device.
 
     Workspaces are cached per (shape, device, STREAM): two forwards of one module on two streams never share scratch
-    (Z / Q / MSG / U live there), so concurrent use of a module from several streams is safe."""
+    (Z / Q / U live there).  The packed weights (and a Database cache) are written once on the stream that first asks for
+    them; an event recorded behind that write is waited on by every other stream before its first read, and a re-pack
+    (weights changed) synchronises the device before the old blob is dropped -- so concurrent use of a module from several
+    streams is safe including the first call on each stream."""
 
     MAX_CACHED_WORKSPACES = 8
 
@@ -191,6 +201,8 @@ class GATsSPGEngine:
         self.lib = _native.load()
         self._packed = None
         self._packed_key = None
+        self._packed_event = None      # recorded on the packing stream right after gatsspg_pack_weights
+        self._packed_stream = None
         self._ws = {}
 
     # ---- weights ----
@@ -213,7 +225,12 @@ class GATsSPGEngine:
         params = self._raw_tensors()
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
         if self._packed is not None and key == self._packed_key:
+            cur = torch.cuda.current_stream(device)
+            if cur.cuda_stream != self._packed_stream:     # another stream: order its reads behind the pack kernels
+                cur.wait_event(self._packed_event)
             return self._packed
+        if self._packed is not None:
+            torch.cuda.synchronize(self._packed.device)    # re-pack: nobody may still be reading the blob that is dropped below
         for p in params:
             _require_gpu(p, "parameter")
         keep = [p.detach().to(device=device, dtype=torch.float32).contiguous() for p in params]
@@ -236,6 +253,9 @@ class GATsSPGEngine:
         with torch.cuda.device(device):
             _native.check(self.lib.gatsspg_pack_weights(ctypes.byref(raw), packed.data_ptr(), _stream(device)),
                           "gatsspg_pack_weights")
+            self._packed_event = torch.cuda.Event()
+            self._packed_event.record(torch.cuda.current_stream(device))
+            self._packed_stream = torch.cuda.current_stream(device).cuda_stream
         self._packed, self._packed_key = packed, key
         return packed
 

@@ -11,8 +11,13 @@ pose leaves HBM only for the final 3x4 matrix (onepose_amd.FrameMatcher).
 
 The checkpoints and the dataset are not part of this repository: when ``<data-dir>/models/checkpoints/onepose/GATsSPG.ckpt``,
 ``<data-dir>/models/extractors/SuperPoint/superpoint_v1.pth`` or the sequences are missing the runner says what it looked
-for and exits with code 0 (BASELINE configs[3] becomes runnable the moment the files appear).  Images are read with PIL
-(the reference uses cv2.imread(..., IMREAD_GRAYSCALE), normalized_dataset.py:24-34: same uint8 luma / 255).
+for and exits with code 0 (BASELINE configs[3] becomes runnable the moment the files appear).  Images are read with PIL and
+converted to luma with OpenCV's fixed-point BGR2GRAY formula (the reference uses cv2.imread(..., IMREAD_GRAYSCALE),
+normalized_dataset.py:24-34), so colour crops give the same uint8 image.
+
+Determinism: the reference seeds every generator with 12345 when inference.py is imported (``seed_everything(12345)``,
+inference.py:13) and draws the leaves of all sequences from that one numpy stream (data_utils.py:163-205).  ``main`` does the
+same -- ``--seed 12345`` (the default) reproduces the reference's leaf selection; the stream continues across sequences.
 """
 from __future__ import annotations
 
@@ -50,8 +55,15 @@ def sequence_paths(seq_dir, sfm_model_dir):
 def read_image(path):
     """NormalizedDataset.__getitem__ (normalized_dataset.py:21-41): grayscale uint8 / 255 as [1,1,H,W] float32."""
     from PIL import Image
-    img = np.asarray(Image.open(path).convert("L"), dtype=np.float32) / 255.0
-    return torch.from_numpy(img)[None, None]
+    im = Image.open(path)
+    if im.mode in ("L", "I;16", "1"):
+        g = np.asarray(im.convert("L"), dtype=np.uint8)
+    else:
+        # OpenCV's 8-bit BGR2GRAY (what IMREAD_GRAYSCALE applies to a colour PNG): fixed point, 14 fractional bits.
+        # PIL's convert("L") rounds differently (16-bit coefficients), which moves some pixels by one LSB.
+        rgb = np.asarray(im.convert("RGB"), dtype=np.int64)
+        g = ((rgb[..., 0] * 4899 + rgb[..., 1] * 9617 + rgb[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+    return torch.from_numpy(g.astype(np.float32) / 255.0)[None, None]
 
 
 def load_models(paths, precision="fp32", device="cuda"):
@@ -62,7 +74,9 @@ def load_models(paths, precision="fp32", device="cuda"):
     matcher.precision = precision
     extractor = SuperPoint({k: v for k, v in SPP_CONF.items() if k != "keypoints_threshold"}).eval()
     sd = torch.load(paths["extractor_model_path"], map_location="cpu")
-    extractor.load_state_dict(sd.get("state_dict", sd) if isinstance(sd, dict) else sd, strict=True)
+    if isinstance(sd, dict):     # model_io.load_network unwraps 'net' (src/utils/model_io.py); Lightning files use 'state_dict'
+        sd = sd.get("net", sd.get("state_dict", sd))
+    extractor.load_state_dict(sd, strict=True)
     return matcher.to(device).eval(), extractor.to(device).eval()
 
 
@@ -100,7 +114,10 @@ def main(argv=None):
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x6"])
     ap.add_argument("--num-leaf", type=int, default=8)
     ap.add_argument("--max-frames", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=12345,
+                    help="numpy global seed set once before the first sequence (12345 = the reference's seed_everything, inference.py:13)")
     a = ap.parse_args(argv)
+    np.random.seed(a.seed)      # one stream for all sequences, like the reference (load_object_database draws from it)
     paths = default_paths(a.data_dir)
     need = [paths["onepose_model_path"], paths["extractor_model_path"], paths["scan_data_dir"], paths["sfm_model_dir"]]
     missing = [q for q in need if not osp.exists(q)]

@@ -38,6 +38,11 @@ def frames_for_rank(n_frames, rank, world):
     return list(range(rank, n_frames, world))
 
 
+def backend_name():
+    """"nccl" (= RCCL on ROCm) / "gloo" when a process group is up (any launch under torchrun, also world 1); None for a bare run."""
+    return dist.get_backend() if dist.is_initialized() else None
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

@@ -11,6 +11,12 @@ unmodified and executed on CPU in fp32 on the seeded synthetic weights / inputs 
   head_b8       BASELINE configs[2]'s per-GPU share: b=8 frames of 1000/7000, random weights, threshold 0
   stress_rand   BASELINE configs[4]  N_3D=20000 dense cloud, b=1, random weights, threshold 0
   stress_planted  same shape, planted matches
+  stress_b4     BASELINE configs[4]'s per-GPU share: b=4 frames of 1000/20000, random weights, threshold 0
+  real_rand     OnePose's own operating point (configs[0]; test_GATsSPG.yaml:21 caps N_3D at 2500, train_GATsSPG.yaml:78-79
+                uses 1000 x 2000): N_2D=500 N_3D=2000 b=1, random weights, threshold 0
+  real_b8       the same shape, 8 frames per step
+
+`python tests/golden/make_bench_golden.py stress_b4 ...` regenerates only the named cases (the meta file keeps the others).
 
 Only reference OUTPUT summaries are stored (inputs and weights are regenerated from seeds): raw row / column arg-max
 indices of every sample, ``pred`` of sample 0, a strided sub-sample of ``conf``, its row/column maxima and sums, and the
@@ -52,6 +58,12 @@ CASES = {
                         hp={"match_threshold": 0.0}, sub=(11, 17)),
     "stress_planted": dict(weights=("passthrough", 0), inputs=dict(b=1, n1=1000, n2=20000, num_leaf=8, seed=6, planted=True),
                            hp={}, sub=(11, 17)),
+    "stress_b4": dict(weights=("random", 0), inputs=dict(b=4, n1=1000, n2=20000, num_leaf=8, seed=7),
+                      hp={"match_threshold": 0.0}, sub=(37, 53)),
+    "real_rand": dict(weights=("random", 0), inputs=dict(b=1, n1=500, n2=2000, num_leaf=8, seed=8),
+                      hp={"match_threshold": 0.0}, sub=(5, 7)),
+    "real_b8": dict(weights=("random", 0), inputs=dict(b=8, n1=500, n2=2000, num_leaf=8, seed=9),
+                    hp={"match_threshold": 0.0}, sub=(11, 13)),
 }
 
 
@@ -100,8 +112,14 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
     meta = {"torch": torch.__version__, "numpy": np.__version__, "cases": {}}
+    only = sys.argv[1:]
+    meta_path = os.path.join(OUT, "bench_golden_meta.json")
+    if only and os.path.exists(meta_path):
+        with open(meta_path) as f:
+            meta["cases"] = json.load(f)["cases"]
     for name, spec in CASES.items():
-        meta["cases"][name] = run_case(name, spec)
+        if not only or name in only:
+            meta["cases"][name] = run_case(name, spec)
     with open(os.path.join(OUT, "bench_golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
 

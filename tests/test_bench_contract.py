@@ -48,6 +48,43 @@ def test_split_bf16_batch8_line():
     assert d["roofline"]["peak"] > 2000 and pc["max_abs_conf_err"] < 1e-4 and pc["argmax_flips"] <= 8 and pc["argmax_checked"] == 64000
 
 
+@gpu
+def test_bf16x6_batch8_is_the_bit_exact_configs2_line():
+    """The configs[2] line that meets north_star's index rule: six-term split, zero arg-max flips against the reference golden."""
+    d = run("--config", "bf16x6-b8", "--steps", "4", "--warmup", "1", "--reps", "2", "--no-cpu-baseline")
+    assert d["dtype"] == "bf16x6" and d["config"]["batch"] == 8 and "configs[2]" in d["config"]["workload"]
+    pc = d["parity_check"]
+    assert pc["max_abs_conf_err"] < 1e-4 and pc["argmax_flips"] == 0 and pc["argmax_checked"] == 64000
+
+
+@gpu
+def test_launched_under_torchrun_world1_runs_the_rccl_path():
+    """The N-rank code path on real hardware at world_size 1: `python -m torch.distributed.run --nproc-per-node 1 bench.py
+    --gpus 1` initialises the nccl (= RCCL) process group, runs the barrier pairs and the device-tensor all_gather the 8-GPU
+    job uses, and its value agrees with the un-launched run of the same protocol (the driver's 'N=1 SCALE agrees with BENCH')."""
+    import socket
+    flags = ["--gpus", "1", "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-side-arithmetics"]
+    plain = run(*flags)
+    assert plain["config"]["process_group"] is None
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), *flags],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["process_group"] == "nccl" and len(d["config"]["per_rank_frames_per_sec"]) == 1
+    assert d["parity_check"]["argmax_flips"] == 0
+    print(f"torchrun world-1 value {d['value']} vs un-launched {plain['value']} ({d['value'] / plain['value'] - 1:+.2%})")
+    assert abs(d["value"] / plain["value"] - 1) < 0.05, (d["value"], plain["value"])   # measured: within 1-2 % (two 5-pass medians)
+
+
 def test_gpus_n_launches_n_ranks_by_itself():
     """`python bench.py --gpus 2` without a torchrun environment spawns 2 ranks (here: CPU stand-in steps over gloo) and
     rank 0 prints one line with n_gpus 2; a WORLD_SIZE that contradicts --gpus is refused, never silently used."""

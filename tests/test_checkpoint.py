@@ -81,3 +81,39 @@ def test_omegaconf_value_nodes_are_unwrapped_not_defaulted(tmp_path):
     sd, got = read_checkpoint(_omegaconf_like_ckpt(tmp_path, hp))
     assert len(sd) == 123
     assert got == hp
+
+
+def test_override_replaces_an_undecodable_hyper_parameter(tmp_path):
+    """A stored value that cannot be decoded raises -- and the override the message suggests really takes effect."""
+    import pytest
+    sd = {"matcher." + k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(3).items()}
+    hp = {"match_threshold": {"_weird": 1, "_node": 2}, "scale_factor": 0.05}
+    path = tmp_path / "odd.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": hp}, path)
+    with pytest.raises(ValueError, match="match_threshold"):
+        read_checkpoint(path)
+    _, got = read_checkpoint(path, overrides={"match_threshold": 0.4})
+    assert got["match_threshold"] == 0.4 and got["scale_factor"] == 0.05
+    model = LitModelGATsSPG.load_from_checkpoint(path, match_threshold=0.4)
+    assert model.matcher.hparams["match_threshold"] == 0.4
+
+
+def test_real_mapping_containers_are_decoded(tmp_path):
+    """hyper_parameters as a Mapping that is not a dict subclass (what omegaconf.DictConfig is when omegaconf IS installed)."""
+    from collections.abc import Mapping
+    from onepose_amd.checkpoint import _plain
+
+    class Cfg(Mapping):
+        def __init__(self, d):
+            self._d = d
+
+        def __getitem__(self, k):
+            return self._d[k]
+
+        def __iter__(self):
+            return iter(self._d)
+
+        def __len__(self):
+            return len(self._d)
+
+    assert _plain(Cfg({"a": Cfg({"b": (1, 2)}), "s": "txt"})) == {"a": {"b": [1, 2]}, "s": "txt"}

@@ -288,10 +288,10 @@ def test_headline_size_vs_oracle_random_weights(precision):
 # the BENCHMARKED shapes against goldens produced by the reference module itself (tests/golden/make_bench_golden.py)
 # ----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("name", ["head_rand", "head_planted", "head_b8", "stress_rand", "stress_planted"])
+@pytest.mark.parametrize("name", ["head_rand", "head_planted", "head_b8", "stress_rand", "stress_planted", "real_rand", "real_b8"])
 def test_benchmarked_shapes_vs_reference_golden(name, precision, bench_golden_meta):
-    """1000/7000 b=1 (bench.py's workload; random weights + planted matches), 1000/7000 b=8 (configs[2]'s per-GPU share)
-    and the 1000/20000 stress shape (configs[4]): conf sub-sample / row+col maxima within 1e-4 of the REFERENCE's own
+    """1000/7000 b=1 (bench.py's workload; random weights + planted matches), 1000/7000 b=8 (configs[2]'s per-GPU share),
+    the 1000/20000 stress shape (configs[4]) and OnePose's own 500/2000 operating point (b=1, b=8: `bench.py --config real`): conf sub-sample / row+col maxima within 1e-4 of the REFERENCE's own
     output, raw arg-max indices and matches identical.  An index may differ only where the reference's top-2 gap is below
     what the arithmetic resolves (conftest.TIE_GAP); the count is printed.  fp32 and bf16x6: zero flips on every case.
     bf16x3: at most a handful per 64000 arg-maxes, each at a reference gap < 1e-3 (measured: one or two, in head_b8)."""
@@ -313,6 +313,21 @@ def test_benchmarked_shapes_vs_reference_golden(name, precision, bench_golden_me
         assert dc < 2e-5
         if flips == 0:
             assert torch.equal(pred["matches0"], pred32["matches0"]) and torch.equal(pred["matches1"], pred32["matches1"])
+
+
+def test_stress_b4_vs_reference_golden(bench_golden_meta):
+    """configs[4]'s per-GPU share (4 frames of 1000/20000 per step, `bench.py --config stress-b4`) against the reference's
+    own output at that shape: conf within 1e-4, arg-max indices identical.  This golden holds four column near-ties below
+    fp32 resolution (reference top-2 relative gaps 6.4e-7, 1.2e-5, 1.8e-5, 1.8e-5 of 84000 arg-maxes): only those may differ
+    (conftest.argmax_flips refuses any other), the count is printed."""
+    mc = bench_golden_meta["cases"]["stress_b4"]
+    g = load_golden("bench_stress_b4")
+    sd, data, hp = case_inputs(mc)
+    pred, conf = make_model(sd, hp, "fp32")(to_dev(data))
+    res = check_bench_golden(conf.cpu().numpy(), {k: v.cpu().numpy() for k, v in pred.items()}, g, mc, CONF_ATOL, "stress_b4[fp32]")
+    print(f"stress_b4 [fp32]: {res}")
+    near_ties = int((g["col_top2_rel_gap"] < TIE_GAP["fp32"]).sum() + (g["row_top2_rel_gap"] < TIE_GAP["fp32"]).sum())
+    assert res["flips_rows"] + res["flips_cols"] <= near_ties == 4
 
 
 def test_keypoint_encoder():

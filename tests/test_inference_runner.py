@@ -66,3 +66,20 @@ def test_runner_end_to_end_on_a_synthetic_tree(tmp_path, capsys):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["frames"] == 3 and d["points_3d"] == 300 and {"cmd1", "cmd3", "cmd5"} <= set(d) and 0.0 <= d["cmd5"] <= 1.0
+
+
+def test_colour_crops_use_opencv_luma_and_main_seeds_the_leaf_stream(tmp_path):
+    """cv2.imread(IMREAD_GRAYSCALE) on a colour PNG = fixed-point BGR2GRAY ((R*4899 + G*9617 + B*1868 + 8192) >> 14); PIL's
+    convert('L') rounds differently.  Known answers of OpenCV's formula, e.g. pure red 255 -> 76, green -> 150, blue -> 29."""
+    from PIL import Image
+    rgb = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255]], [[255, 255, 255], [12, 200, 77], [1, 2, 3]]], dtype=np.uint8)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c.png")
+    t = ir.read_image(str(tmp_path / "c.png"))
+    want = np.array([[76, 150, 29], [255, (12 * 4899 + 200 * 9617 + 77 * 1868 + 8192) >> 14, 2]], dtype=np.float32) / 255.0
+    np.testing.assert_array_equal(t[0, 0].numpy(), want)
+    # main() seeds numpy's global stream (the reference's seed_everything(12345), inference.py:13) even when it has nothing to do
+    np.random.seed(1)
+    ir.main(["--data-dir", str(tmp_path)])
+    a = np.random.permutation(10)
+    np.random.seed(12345)
+    np.testing.assert_array_equal(a, np.random.permutation(10))
