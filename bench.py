@@ -58,10 +58,10 @@ def f_alg(n1, n2, L, d=256):
 def kernel_flops(name, n1, n2):
     """Useful flops EXECUTED per launch on the real (unpadded) points."""
     n = n1 + n2
-    return {"mlp0": 2 * 512 * 512 * n,          # [512x512] x [x ; msg]  (merge folded in: algorithmic 10 d^2 n)
+    return {"mlp0": 2 * 512 * 512 * n,          # [512x512] x [x ; Qf]  (merge and the attention apply folded in: algorithmic 10 d^2 n + 2 d dh n)
             "qkv_kv": 2 * 768 * 256 * n + 2 * 256 * 64 * n,
             "mlp3": 2 * 256 * 512 * n,
-            "score_exp": 2 * n1 * n2 * 256, "gats": 16 * n2 * 256 * 9, "final_proj_norm": 2 * 256 * 256 * n, "attn_apply": 2 * 256 * 64 * n}.get(name, 1)
+            "score_exp": 2 * n1 * n2 * 256, "gats": 16 * n2 * 256 * 9, "final_proj_norm": 2 * 256 * 256 * n}.get(name, 1)
 
 
 class Weights:

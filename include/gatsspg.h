@@ -108,7 +108,7 @@ int gatsspg_forward(const float* packed, const float* desc2d_query, const float*
 
 /* Same forward, with a HIP-event bracket (hipEvent_t, created by the caller, recorded on `stream`)
  * around the `occurrence`-th launch of one kernel -- how bench.py times the dominant kernel live.
- * kernel_id: 0 load_state (only when the first GATs launch cannot fuse it), 1 gats, 2 qkv_kv, 3 kv_final, 4 attn_apply,
+ * kernel_id: 0 load_state (only when the first GATs launch cannot fuse it), 1 gats, 2 qkv_kv, 3 kv_final (KV sums + the message operators M_t of mlp.0), 4 retired (the former attn_apply launch: folded into 3 and 5),
  * 5 mlp0, 6 stat_final, 7 mlp3, 8 final_proj_norm, 9 score_exp, 10 conf_finalize, 11 match_tail, 12 gats_wlt,
  * 13 softmax_stats (max-subtracting path only). */
 int gatsspg_forward_profiled(const float* packed, const float* desc2d_query, const float* desc3d_db,

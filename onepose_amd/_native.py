@@ -16,7 +16,7 @@ FLAG_INCLUDE_SELF, FLAG_ADDITIONAL, FLAG_WITH_LINEAR_TRANSFORM = 1, 2, 4
 FLAG_PREC_BF16X3 = 0x100
 FLAG_PREC_BF16X6 = 0x200
 PRECISIONS = {"fp32": 0, "bf16x3": FLAG_PREC_BF16X3, "bf16x6": FLAG_PREC_BF16X6}   # GEMM arithmetic of the attention layers, selected per call
-KERNEL_IDS = {"load_state": 0, "gats": 1, "qkv_kv": 2, "kv_final": 3, "attn_apply": 4, "mlp0": 5, "stat_final": 6,
+KERNEL_IDS = {"load_state": 0, "gats": 1, "qkv_kv": 2, "kv_final": 3, "mlp0": 5, "stat_final": 6,
               "mlp3": 7, "final_proj_norm": 8, "score_exp": 9, "conf_finalize": 10, "match_tail": 11, "gats_wlt": 12,
               "softmax_stats": 13}
 LAYER_SELF, LAYER_CROSS = 0, 1

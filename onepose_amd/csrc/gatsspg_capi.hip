@@ -90,7 +90,7 @@ void enqueue_attn(const float* packed, int layer, int kind, const Workspace& w, 
     const float* a = attn_w(packed, layer);
     const unsigned short* ab = attn_wb(packed, layer);
     launch_qkv_kv(a + AttnW::WQKV, a + AttnW::BQKV, ab, w, s, hk);
-    launch_attn_apply(w, kind == GATSSPG_LAYER_CROSS, s, hk);
+    launch_kv_final(a + AttnW::W0, w, kind == GATSSPG_LAYER_CROSS, nullptr, s, hk);
     launch_mlp(a + AttnW::W0, a + AttnW::B0, a + AttnW::W3, a + AttnW::B3, ab, w, s, hk);
 }
 
@@ -286,6 +286,7 @@ int gatsspg_prepare_database(const float* packed, const float* desc3d_db, const 
     enqueue_attn(packed, 0, GATSSPG_LAYER_SELF, wy, s);                     // gnn.layers.1, 3D side
     const float* a1 = attn_w(packed, 1);
     launch_qkv_kv(a1 + AttnW::WQKV, a1 + AttnW::BQKV, attn_wb(packed, 1), wy, s);   // gnn.layers.2: 3D-side Q, KV, ksum
+    launch_kv_final(a1 + AttnW::W0, wy, 1, nullptr, s);                             //   (the final sums land in w.kvfin)
     launch_store_state(w.Z, nullptr, c.Y2, w, s);
     launch_store_state(w.Q, nullptr, c.QY, w, s);
     if (hipMemcpy2DAsync(c.kvY, sizeof(float) * H * KVP, w.kvfin + (size_t)H * KVP, sizeof(float) * 2 * H * KVP,
@@ -313,11 +314,8 @@ int gatsspg_forward_cached(const float* packed, const float* desc2d_query, const
     enqueue_attn(packed, 0, GATSSPG_LAYER_SELF, wx, s);                     // gnn.layers.1, query side only
     const float* a1 = attn_w(packed, 1);
     launch_qkv_kv(a1 + AttnW::WQKV, a1 + AttnW::BQKV, attn_wb(packed, 1), wx, s);   // gnn.layers.2: query-side Q, KV, ksum
-    launch_load_columns(nullptr, c.QY, w.Q, w, s);                          // 3D-side Q and KV sums from the cache
-    if (hipMemcpy2DAsync(w.kvfin + (size_t)H * KVP, sizeof(float) * 2 * H * KVP, c.kvY, sizeof(float) * H * KVP,
-                         sizeof(float) * H * KVP, b, hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return fail("forward_cached: copy of the KV sums failed");
-    launch_attn_apply(w, 1, s);
+    launch_load_columns(nullptr, c.QY, w.Q, w, s);                          // 3D-side Q from the cache
+    launch_kv_final(a1 + AttnW::W0, w, 1, c.kvY, s);                        // query-side sums from the partials, 3D-side sums from the cache
     launch_mlp(a1 + AttnW::W0, a1 + AttnW::B0, a1 + AttnW::W3, a1 + AttnW::B3, attn_wb(packed, 1), w, s);
     const bool cached_logits = gats_caches_leaf_logits(num_leaf, flags);
     for (int t = 1; t < 4; ++t) {

@@ -12,7 +12,9 @@ constexpr int H = 4;      // heads (GATs_SuperGlue.py:43)
 constexpr int DH = 64;    // channels per head
 constexpr int CP = 128;   // column padding granule: every (frame, side) segment starts on a multiple of CP
 constexpr int BK = 32;    // K tile of every MFMA GEMM
-constexpr int KVP = DH * DH + DH;  // one KV partial: 64x64 KV matrix [q][d] + 64 ksum
+constexpr int KVP = DH * DH + DH;  // one KV partial: the 64x64 KV matrix TRANSPOSED, [d][q] (kv_final owns 4-row d blocks), + 64 ksum
+constexpr int MOP_LD = 512;        // row stride of the per-segment message operators M_seg [512][256] (two segments share a [512][512] block)
+constexpr int MPL_PLANE = 512 * 256;   // bf16 elements of one split plane of M_seg (slab-major like the weight planes)
 
 // tile widths baked into the partial-sum buffers
 constexpr int QKV_BN = 64;    // column tile of the QKV+KV-partial kernel (one KV partial per tile)
@@ -122,9 +124,14 @@ struct Workspace {
     int nseg;          // 2*b
     int sc_nct, sc_nrt;   // score kernel tiles per frame (n2p/SC_BN, n1p/SC_BM)
     int cf_nst, cf_nch;   // conf-finalize strips / chunks per frame
-    float *Z, *Q, *MSG, *U, *MD;     // MD aliases Q (Q is dead after the GNN)
+    float *Z, *Q, *MSG, *U, *MD;     // MD aliases Q (Q is dead after the GNN); MSG: scratch of the with_linear_transform GATs path
     float *MDT;                      // query-side normalised descriptors, point-major [b][n1p][256]; aliases MSG
     float *kvpart, *kvfin, *statpart, *stats;
+    // linear attention folded into mlp.0 (kv_final_kernel -> mlp0_kernel): per TARGET segment t the operator
+    // M_t = (W0b Wm)[:, head h] KV_h(source) for the four heads [512][4 x 64], and the source's ksum.
+    float *Mop;                      // [b][512][512]: segment 2f at columns 256..511, segment 2f+1 at columns 0..255 of frame f's block
+    unsigned short *Mpl;             // split-bf16 planes of M_t (prec != 0): [nseg][3][8 slabs][512][32]
+    float *ksumT;                    // [nseg][4][64]
     float *rowpart, *colpart, *rs, *cs;
     float *rmax_v, *cmax_v, *rshift, *cshift;   // rshift / cshift: row / column maxima of the max-subtracting dual softmax
     int *rmax_i, *cmax_i;
@@ -132,6 +139,12 @@ struct Workspace {
 };
 
 inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+// M_t of segment `seg`: element (r, c), c = h*64 + d, at mop_seg(Mop, seg)[r * MOP_LD + c]
+__host__ __device__ inline float* mop_seg(float* Mop, int seg) { return Mop + (size_t)(seg >> 1) * 512 * MOP_LD + ((seg & 1) ? 0 : 256); }
+__host__ __device__ inline const float* mop_seg(const float* Mop, int seg) {
+    return Mop + (size_t)(seg >> 1) * 512 * MOP_LD + ((seg & 1) ? 0 : 256);
+}
 
 inline Workspace carve_workspace(void* base, int b, int n1, int n2) {
     Workspace w;
@@ -156,6 +169,9 @@ inline Workspace carve_workspace(void* base, int b, int n1, int n2) {
     w.MDT = w.MSG;   // b * n1p * 256 floats <= 256 * ld
     w.kvpart = (float*)take(sizeof(float) * (size_t)w.nt64 * H * KVP);
     w.kvfin = (float*)take(sizeof(float) * (size_t)w.nseg * H * KVP);
+    w.Mop = (float*)take(sizeof(float) * (size_t)b * 512 * MOP_LD);
+    w.Mpl = (unsigned short*)take(sizeof(unsigned short) * (size_t)w.nseg * 3 * MPL_PLANE);
+    w.ksumT = (float*)take(sizeof(float) * (size_t)w.nseg * H * DH);
     w.statpart = (float*)take(sizeof(float) * (size_t)w.nt64 * 2 * 512);
     w.stats = (float*)take(sizeof(float) * (size_t)w.nseg * 2 * 512);
     w.rowpart = (float*)take(sizeof(float) * (size_t)b * w.sc_nct * L.n1p);

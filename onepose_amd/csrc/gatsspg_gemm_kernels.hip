@@ -7,12 +7,28 @@
 
 namespace gatsspg {
 
+// dynamic LDS of a main loop (operand stages; the epilogues re-use it)
+template <class T, int PREC = 0>
+constexpr size_t smem_bytes() {
+    size_t b = sizeof(float) * T::SMEM_FLOATS;
+    if constexpr (PREC == 1) {
+        if (Bf3Layout<T>::SMEM_BYTES > b) b = Bf3Layout<T>::SMEM_BYTES;
+    }
+    if constexpr (PREC == 2) {
+        if (Bf6Layout<T>::SMEM_BYTES > b) b = Bf6Layout<T>::SMEM_BYTES;
+    }
+    return b;
+}
+template <class T, int PREC>
+constexpr int smem_floats_mainloop() { return (int)(smem_bytes<T, PREC>() / sizeof(float)); }
+
 // =====================================================================================================
 // K1  QKV projection fused with the linear-attention KV / ksum partial reduction.
 //     rows 0..255  : Q = elu(Wq x + bq) + 1  (head-major), written to Qbuf
 //     rows 256..767: per head h a 128-row tile [K_h ; V_h]; K = elu(.)+1, V raw.  K and V are
 //                    never written to HBM: the tile goes to LDS and a second MFMA pass produces
-//                    this column tile's partial  KV_h[q][d] = sum_m V[q][m] K[d][m],  ksum_h[d].
+//                    this column tile's partial  KV_h[q][d] = sum_m V[q][m] K[d][m]  (stored transposed, [d][q]:
+//                    kv_final_kernel owns blocks of d rows),  ksum_h[d].
 //     (GATs_SuperGlue.py:96-99 projections, :71-72 feature map, :77-78 KV and key.sum)
 // =====================================================================================================
 using QkvTileW8 = GemmTile<128, QKV_BN, 4, 2, false>;     // both arithmetics: 8 waves, one 32x32 MFMA tile each (fp32: 38.0 vs 40.1 us on 4 waves)
@@ -99,13 +115,13 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void qkv_kv_kernel
         }
     __syncthreads();
     if (wave < 4) {   // (an 8-wave workgroup leaves this short pass to its first four waves: same order of operations)
-        // wave -> 32x32 quadrant (qi, di) of KV[q][d]; contraction over the 64 columns m
+        // wave -> 32x32 quadrant (di, qi) of KV^T[d][q]; contraction over the 64 columns m (A operand = K rows, B operand = V rows)
         const int qi = wave >> 1, di = wave & 1;
         f32x16 kv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) kv[r] = 0.f;
-        const float4* ap = reinterpret_cast<const float4*>(Tl + (64 + qi * 32 + l31) * TS + half * 32);
-        const float4* bp = reinterpret_cast<const float4*>(Tl + (di * 32 + l31) * TS + half * 32);
+        const float4* ap = reinterpret_cast<const float4*>(Tl + (di * 32 + l31) * TS + half * 32);
+        const float4* bp = reinterpret_cast<const float4*>(Tl + (64 + qi * 32 + l31) * TS + half * 32);
 #pragma unroll
         for (int v4 = 0; v4 < 8; ++v4) {
             const float4 a = ap[v4], b = bp[v4];
@@ -117,8 +133,8 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void qkv_kv_kernel
         float* out = kvpart + ((size_t)ct * H + h) * KVP;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int q = qi * 32 + mfma_row(r, half);
-            out[q * DH + di * 32 + l31] = kv[r];
+            const int d = di * 32 + mfma_row(r, half);
+            out[d * DH + qi * 32 + l31] = kv[r];
         }
         {   // ksum[d] = sum_m K[d][m]: 4 lanes per row (16 columns each, fixed order), combined by 2 shuffles
             const int d = tid >> 2, qtr = tid & 3;
@@ -133,25 +149,66 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void qkv_kv_kernel
     }
 }
 
-// K2  fixed-order sum of the KV partials of each (segment, head) -> KV[seg][h][q][d], ksum[seg][h][d].
+// K2  fixed-order sum of the KV partials of each (SOURCE segment, head) -> KV^T[seg][h][d][q], ksum[seg][h][d], and -- what
+//     replaces the former attn_apply launch and the MSG round trip -- the message operator of the TARGET segment
+//     (the same segment for 'self', the other side of the same frame for 'cross', GATs_SuperGlue.py:57,62):
+//         M_t[:, h*64 + d] = sum_q (W0b Wm)[:, h*64 + q] KV_h[q][d]            [512 x 256]
+//     so that mlp.0's message half  (W0b Wm) msg,  msg_h[q][n] = z_h[n] sum_d KV_h[q][d] Qf_h[d][n]  (:78-79,101,122),
+//     becomes  sum_h z_h[n] (M_h Qf_h)[.][n]  inside mlp0_kernel's K loop (AttnFoldHooks).
 //     1024 threads = 64 float4 elements x 16 tile-ranges: every range is summed in tile order by one wave
 //     (8 independent 16-byte loads in flight at a time on clamped addresses -- a plain unrolled loop leaves a serial
 //     remainder loop, one load and one s_waitcnt vmcnt(0) per iteration), the 16 range sums are combined in range
-//     order -> the result does not depend on scheduling.  136 workgroups at the headline shape: one round (the
-//     one-float-per-thread form needed 520 workgroups of 16 waves on 512 slots -- 1.02 rounds).
+//     order -> the result does not depend on scheduling.  A block owns 4 d rows (all 64 q) of one head: exactly what the
+//     4 columns of M it then produces need -- no cross-workgroup dependency.  The weights of the output rows are requested
+//     BEFORE the reduction (independent of it).  The operator phase is LDS-bound (every KV value a thread multiplies comes
+//     through a ds_read: rows x 1 KB per block), so a thread takes TWO rows per KV read and two workgroups share the rows of a
+//     d block (each repeats the reduction).  The last block of a (segment, head) owns ksum.
+//     kv_src (amortised mode): final KV sums of the 3D-side sources from the database cache; they are read as a single
+//     partial (0 + x = x: same bits as reducing the partials again).
 constexpr int KVP4 = KVP / 4;
 static_assert(KVP % 4 == 0, "KV partials are summed as float4");
+constexpr int KVF_RS = 2;                       // row halves of M_t per d block: two workgroups repeat the (cheap, parallel) reduction and
+constexpr int KVF_ROWS = 512 / KVF_RS;          //   each turns it into 256 rows of the operator -> 264 workgroups, every CU busy
+constexpr int KVF_BLOCKS = 16 * KVF_RS + 1;     // 16 d-row blocks x row halves + the ksum block
 
-__global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict__ kvpart, float* __restrict__ kvfin,
-                                                        ColLayout L) {
+// abl (tuning builds only, wrong results, 0 in the product): bit 0 no FMA phase, bit 1 no operator stores, bit 2 no weight loads
+__global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict__ kvpart, const float* __restrict__ kv_src,
+                                                        float* __restrict__ kvfin, const float* __restrict__ W0,
+                                                        float* __restrict__ Mop, unsigned short* __restrict__ Mpl,
+                                                        float* __restrict__ ksumT, ColLayout L, int cross, int prec, int abl) {
     __shared__ float4 red[16][64];
-    const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int e4 = min((int)blockIdx.x * 64 + el, KVP4 - 1);   // clamped: the last block's spare lanes redo element KVP4 - 1
+    __shared__ float4 kvs[64];   // this block's final KV^T rows: [4 d][16 float4 of q]
+    const int tid = threadIdx.x;
+    const int el = tid & 63, part = tid >> 6;
+    const bool ksum_block = blockIdx.x == 16 * KVF_RS;
+    const int db = ksum_block ? 16 : blockIdx.x / KVF_RS, rs = blockIdx.x % KVF_RS;
+    const int e4 = min(db * 64 + el, KVP4 - 1);   // clamped: the last block's spare lanes redo element KVP4 - 1
     const int seg = blockIdx.y / H, h = blockIdx.y % H;
     const int frame = seg >> 1, side = seg & 1;
     if (!((L.side_mask >> side) & 1)) return;
-    const int t0 = (frame * L.np + (side ? L.n1p : 0)) / QKV_BN;
-    const int nt = (side ? L.n2p : L.n1p) / QKV_BN;
+    const int tseg = cross ? (seg ^ 1) : seg;
+    // operator phase: thread = (row pair rp, q quarter qq); lane qq takes the float4s qq, qq + 4, qq + 8, qq + 12 of the 64 q of a
+    // row (the 4 lanes of a row read 64 contiguous bytes per load).  The weights do not depend on the reduction: requested first.
+    const int rp = (tid >> 2) & 127, qq = tid & 3;
+    const int mr = rs * KVF_ROWS + 2 * rp;
+    vf4 wv[2][4];
+    const bool op_thread = !ksum_block && tid < 512;
+    if (op_thread && !(abl & 4)) {
+        const float* wr = W0 + (size_t)mr * 512 + 256 + h * DH + 4 * qq;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[e][i] = ldg4(wr + e * 512 + 16 * i);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[e][i] = (vf4){1.f, 2.f, 3.f, 4.f};
+    }
+    const bool cached = kv_src != nullptr && side == 1;
+    const float* base = cached ? kv_src + ((size_t)frame * H + h) * KVP
+                               : kvpart + ((size_t)((frame * L.np + (side ? L.n1p : 0)) / QKV_BN) * H + h) * KVP;
+    const int nt = cached ? 1 : (side ? L.n2p : L.n1p) / QKV_BN;
     const int per = (nt + 15) / 16;
     const int tb = part * per, te = min(nt, tb + per);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -159,106 +216,95 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
         float4 x[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            x[u] = *reinterpret_cast<const float4*>(kvpart + ((size_t)(t0 + min(tt + u, nt - 1)) * H + h) * KVP + 4 * e4);
+            x[u] = *reinterpret_cast<const float4*>(base + (size_t)min(tt + u, nt - 1) * H * KVP + 4 * e4);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (tt + u < te) { s.x += x[u].x; s.y += x[u].y; s.z += x[u].z; s.w += x[u].w; }
     }
     red[part][el] = s;
     __syncthreads();
-    if (part == 0 && (int)blockIdx.x * 64 + el < KVP4) {
+    if (part == 0) {
         float4 tot = red[0][el];
 #pragma unroll
         for (int p = 1; p < 16; ++p) {
             const float4 r = red[p][el];
             tot.x += r.x; tot.y += r.y; tot.z += r.z; tot.w += r.w;
         }
-        *reinterpret_cast<float4*>(kvfin + ((size_t)seg * H + h) * KVP + 4 * e4) = tot;
+        kvs[el] = tot;
+        if (db * 64 + el < KVP4 && rs == 0) {
+            *reinterpret_cast<float4*>(kvfin + ((size_t)seg * H + h) * KVP + 4 * e4) = tot;
+            if (ksum_block) *reinterpret_cast<float4*>(ksumT + ((size_t)tseg * H + h) * DH + 4 * el) = tot;   // ksum of the source
+        }
+    }
+    if (ksum_block) return;
+    __syncthreads();
+    if (!op_thread) return;
+    // M_t[mr + e][h*64 + 4 db + j] = sum_q W[mr + e][q] KV^T[4 db + j][q]:  four lanes per row (16 q each, fixed order), combined
+    // by two exchange steps ((l0 + l1) + (l2 + l3) on every lane)
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (!(abl & 1)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 k4 = kvs[j * 16 + qq + 4 * i];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    acc[e][j] = fmaf(wv[e][i][0], k4.x, acc[e][j]);
+                    acc[e][j] = fmaf(wv[e][i][1], k4.y, acc[e][j]);
+                    acc[e][j] = fmaf(wv[e][i][2], k4.z, acc[e][j]);
+                    acc[e][j] = fmaf(wv[e][i][3], k4.w, acc[e][j]);
+                }
+            }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[e][j] = wv[e][j][0] + kvs[qq].x;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[e][j];
+            const float o1 = __shfl_xor(v, 1);
+            v = (qq & 1) ? o1 + v : v + o1;          // lower lane's value first on both lanes
+            const float o2 = __shfl_xor(v, 2);
+            acc[e][j] = (qq & 2) ? o2 + v : v + o2;
+        }
+    if (qq >= 2 || (abl & 2)) return;
+    // lane qq = 0 stores row mr, lane qq = 1 row mr + 1 (all four lanes hold both sums)
+    const int row = mr + qq;
+    const float o0 = qq ? acc[1][0] : acc[0][0], o1 = qq ? acc[1][1] : acc[0][1], o2 = qq ? acc[1][2] : acc[0][2],
+                o3 = qq ? acc[1][3] : acc[0][3];
+    const int c = h * DH + 4 * db;   // first of this block's 4 columns of M_t
+    if (prec == 0) {
+        vf4 v = {o0, o1, o2, o3};
+        *reinterpret_cast<vf4*>(mop_seg(Mop, tseg) + (size_t)row * MOP_LD + c) = v;
+    } else {
+        // split planes in the slab-major layout of the weight planes: (m, k) at ((k / 32) * 512 + m) * 32 + k % 32
+        unsigned p0a, p1a, p2a, p0b, p1b, p2b;
+        bf16_split3(o0, o1, p0a, p1a, p2a);
+        bf16_split3(o2, o3, p0b, p1b, p2b);
+        unsigned short* pl = Mpl + (size_t)tseg * 3 * MPL_PLANE + ((size_t)(c >> 5) * 512 + row) * 32 + (c & 31);
+        *reinterpret_cast<u32x2*>(pl) = (u32x2){p0a, p0b};
+        *reinterpret_cast<u32x2*>(pl + MPL_PLANE) = (u32x2){p1a, p1b};
+        if (prec == 2) *reinterpret_cast<u32x2*>(pl + 2 * MPL_PLANE) = (u32x2){p2a, p2b};
     }
 }
 
 // =====================================================================================================
-// K3  linear-attention apply:  msg_h[q][n] = z_h[n] * sum_d KV_h[q][d] Q_h[d][n],
-//     z_h[n] = 1 / (sum_d Q_h[d][n] ksum_h[d] + 1e-6)          (GATs_SuperGlue.py:78-79; the
-//     value/v_length ... *v_length pair of :74-75,79 cancels and is not evaluated)
-//     KV / ksum come from the source segment: the same segment for 'self', the other side of the
-//     same frame for 'cross' (:57,62).
-// =====================================================================================================
-// One workgroup = one (64-column tile, head): K = 64 is two MFMA slabs, so there is nothing to pipeline -- KV_h, ksum_h and the
-// Q_h tile are fetched in one go into LDS (one barrier), z comes from the LDS copy of Q, four waves do one 32x32 tile each.
-constexpr int AP_AS = DH + 4;   // LDS row stride of KV_h [q][d]: b128 fragment reads conflict-free (17 * row mod 16 is a bijection)
-
-__global__ __launch_bounds__(256) void attn_apply_kernel(const float* __restrict__ kvfin, const float* __restrict__ Qbuf,
-                                                         float* __restrict__ MSG, ColLayout L, int cross) {
-    __shared__ __attribute__((aligned(16))) float KVs[DH * AP_AS];
-    __shared__ __attribute__((aligned(16))) float Qs[DH * 64];
-    __shared__ float ks[DH];
-    __shared__ float zpart[4][64];
-    const int ct = global_tile(L, blockIdx.x >> 2), h = blockIdx.x & 3;
-    const int c0 = ct * 64, ld = L.ld;
-    const TileSeg ts = tile_seg(L, c0, 64);
-    const int src = cross ? (ts.seg ^ 1) : ts.seg;
-    const float* KV = kvfin + ((size_t)src * H + h) * KVP;  // [q][d]
-    const float* Qh = Qbuf + (size_t)h * DH * ld + c0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {
-        vf4 kvr[4], qr[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int idx = p * 256 + tid, row = idx >> 4, c4 = (idx & 15) * 4;
-            kvr[p] = ldg4(KV + row * DH + c4);
-            qr[p] = ldg4(Qh + (size_t)row * ld + c4);
-        }
-        if (tid < DH) ks[tid] = KV[DH * DH + tid];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int idx = p * 256 + tid, row = idx >> 4, c4 = (idx & 15) * 4;
-            *reinterpret_cast<vf4*>(KVs + row * AP_AS + c4) = kvr[p];
-            *reinterpret_cast<vf4*>(Qs + row * 64 + c4) = qr[p];
-        }
-    }
-    __syncthreads();
-    {   // z denominators: 4 partial sums of 16 channels per column, combined in a fixed order below
-        const int col = lane, part = wave;
-        float s = 0.f;
-#pragma unroll
-        for (int d = part * 16; d < part * 16 + 16; ++d) s += Qs[d * 64 + col] * ks[d];
-        zpart[part][col] = s;
-    }
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {   // two 32-wide k slabs; lane half 0 takes k = s, half 1 takes k = 16 + s of each
-        const vf4* ap = reinterpret_cast<const vf4*>(KVs + (wm * 32 + l31) * AP_AS + kk * 32 + half * 16);
-        const float* bp = Qs + (kk * 32 + half * 16) * 64 + wn * 32 + l31;
-#pragma unroll
-        for (int v4 = 0; v4 < 4; ++v4) {
-            const vf4 a = ap[v4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bp[(v4 * 4 + e) * 64], acc, 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    const int col = wn * 32 + l31;
-    const float z = 1.f / (((zpart[0][col] + zpart[1][col]) + (zpart[2][col] + zpart[3][col])) + 1e-6f);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q = wm * 32 + mfma_row(r, half);
-        MSG[(size_t)(h * DH + q) * ld + c0 + col] = acc[r] * z;
-    }
-}
-
-// =====================================================================================================
-// K4  mlp.0 with merge folded in:  u = W0a x + (W0b Wm) msg + (b0 + W0b bm)   [512 x N]
-//     (GATs_SuperGlue.py:101 merge, :113 cat, :122 first Conv1d) + per-tile InstanceNorm partials
+// K4  mlp.0 with merge AND the linear-attention apply folded in:
+//         u = W0a x + sum_h z_h (.) (M_h Qf_h) + (b0 + W0b bm)   [512 x N]
+//     M_h = (W0b Wm)[:, head h] KV_h of the tile's segment (kv_final_kernel), Qf = elu(q) + 1 (qkv_kv_kernel),
+//     z_h[n] = 1 / (Qf_h[:, n] . ksum_h + 1e-6)  -- K loop over [x ; Qf], AttnFoldHooks (gemm_f32_mfma.h)
+//     (GATs_SuperGlue.py:78-79 linear attention, :101 merge, :113 cat, :122 first Conv1d) + per-tile InstanceNorm partials
 //     (sum u, sum u^2 over the tile's real columns; :126).
 // =====================================================================================================
 // tiles (one InstanceNorm partial per 64-column tile whatever BN is)
-using Mlp0TileW8 = GemmTile<128, MLP0_BN, 4, 2, false>;       // both arithmetics: 8 waves, one 32x32 MFMA tile each (fp32: 43.1 vs 45.0 us on 4 waves)
-using Mlp0TileW16 = GemmTile<128, 2 * MLP0_BN, 4, 4, false>;  // fp32 alternative (tuning builds): 128x128 on 16 waves, one workgroup per CU
-using Mlp0TileB8 = GemmTile<128, 2 * MLP0_BN, 2, 4, false>;   // split-bf16 alternative (tuning builds): 128x128 on 8 waves (kernel -4 %, frames/s equal)
+using Mlp0TileW8 = GemmTile<128, MLP0_BN, 4, 2, false>;       // all arithmetics: 8 waves, one 32x32 MFMA tile each (fp32: 43.1 vs 45.0 us on 4 waves)
+// (round 2 also measured 128x128 tiles -- 16 waves fp32: kernel -3 %, frames/s in flight -0.8 %; 8 waves split-bf16: kernel -4 %,
+//  frames/s equal; the attention fold needs thread = (k group, column) on a 64-column tile, they are gone)
 
 // per-workgroup timeline of mlp0_kernel (tools/trace_mlp0.py): 8 x u64 per workgroup
 // [hw_id, xcc_id, t_entry, shader cycles, t_after_mainloop, t_end, rt, ct], 100 MHz wall clock.
@@ -274,7 +320,9 @@ template <class T, int ABL = 0, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                    const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
                                                    const unsigned short* __restrict__ Wl2,
-                                                   const float* __restrict__ Z, const float* __restrict__ MSG,
+                                                   const float* __restrict__ Z, const float* __restrict__ Qbuf,
+                                                   const float* __restrict__ Mop, const unsigned short* __restrict__ Mpl,
+                                                   const float* __restrict__ ksumT,
                                                    float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
                                                    unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -307,24 +355,39 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp0_kernel(c
     // ABL == 5 (profiling): every workgroup streams the SAME weight panel and the SAME column tile (cache-hot operands)
     const float* Ah = ABL == 5 ? W0 : A;
     const int ch0 = ABL == 5 ? 0 : c0;
-    auto al = [&](int kt) { return Ah + kt * BK; };
-    auto bl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : MSG + (size_t)(kt - 8) * BK * ld) + ch0; };
+    const TileSeg ts = tile_seg(L, c0, T::BN);   // segments start on multiples of 128 columns: a tile never straddles two
+    // K slabs 0..7: the x half of W0 against the state; slabs 8..15: this segment's message operator against Qf
+    const float* Am = mop_seg(Mop, ts.seg) + (size_t)rt * T::BM * MOP_LD;
+    static_assert(MOP_LD == 512, "the message operator shares the row stride of W0");
+    auto al = [&](int kt) { return kt < 8 ? Ah + kt * BK : Am + (kt - 8) * BK; };
+    auto bl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : Qbuf + (size_t)(kt - 8) * BK * ld) + ch0; };
+    AttnFoldHooks hooks;
+    hooks.init(ksumT + (size_t)ts.seg * H * DH, smem + smem_floats_mainloop<T, PREC>(), wn);
     if constexpr (PREC == 1) {
-        const size_t ro = (size_t)rt * T::BM * BK;   // slab-major planes (see qkv_kv_kernel)
+        const size_t ro = (size_t)rt * T::BM * BK;   // slab-major planes (see qkv_kv_kernel); M_t planes in the same layout
+        const unsigned short* Mh = Mpl + (size_t)ts.seg * 3 * MPL_PLANE + ro;
         gemm_mainloop_bf3<T>(
-            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, [&](int kt) { return Whi + ro + (size_t)kt * 512 * BK; },
-            [&](int kt) { return Wlo + ro + (size_t)kt * 512 * BK; }, BK, bl, ld);
+            acc, reinterpret_cast<unsigned short*>(smem), 512 / BK,
+            [&](int kt) { return kt < 8 ? Whi + ro + (size_t)kt * 512 * BK : Mh + (size_t)(kt - 8) * 512 * BK; },
+            [&](int kt) { return kt < 8 ? Wlo + ro + (size_t)kt * 512 * BK : Mh + MPL_PLANE + (size_t)(kt - 8) * 512 * BK; }, BK, bl, ld,
+            &hooks);
     } else if constexpr (PREC == 2) {
         const size_t ro = (size_t)rt * T::BM * BK;
+        const unsigned short* Mh = Mpl + (size_t)ts.seg * 3 * MPL_PLANE + ro;
         gemm_mainloop_bf6<T>(
             acc, reinterpret_cast<unsigned short*>(smem), 512 / BK,
-            [&](int kt, int pl) { return (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + (size_t)kt * 512 * BK; }, BK, bl, ld);
+            [&](int kt, int pl) {
+                return kt < 8 ? (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + (size_t)kt * 512 * BK
+                              : Mh + (size_t)pl * MPL_PLANE + (size_t)(kt - 8) * 512 * BK;
+            },
+            BK, bl, ld, &hooks);
     } else {
-        gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL)>(acc, smem, 512 / BK, al, 512, bl, ld);
+        gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL), IdentityCol, AttnFoldHooks>(acc, smem, 512 / BK, al, 512, bl, ld,
+                                                                                                      IdentityCol(), &hooks);
     }
+    acc[0][0] = hooks.kept;
     if constexpr (PREC == 2) load_bias();
     const unsigned long long t_loop = trace ? wall_clock64() : 0;
-    const TileSeg ts = tile_seg(L, c0, T::BN);
     constexpr int TS = T::BN + 1;
     float* Tl = smem;  // [BM][BN + 1]
 #pragma unroll
@@ -742,17 +805,6 @@ void launch_split_weights(const float* packed, unsigned short* packedb, hipStrea
 // ------------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------------
-template <class T, int PREC = 0>
-constexpr size_t smem_bytes() {
-    size_t b = sizeof(float) * T::SMEM_FLOATS;
-    if constexpr (PREC == 1) {
-        if (Bf3Layout<T>::SMEM_BYTES > b) b = Bf3Layout<T>::SMEM_BYTES;
-    }
-    if constexpr (PREC == 2) {
-        if (Bf6Layout<T>::SMEM_BYTES > b) b = Bf6Layout<T>::SMEM_BYTES;
-    }
-    return b;
-}
 
 // Kernels whose dynamic LDS request exceeds the 64 KiB default need the limit raised once per device.  The once-flag
 // lives in a function template instantiated per KERNEL (the kernel is a non-type template argument), so two variants
@@ -786,13 +838,12 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* w
     else if (w.prec == 1) launch_qkv_t<QkvTileW8, 1>(Wqkv, bqkv, wb, w, s, hk);
     else if (w.prec == 2) launch_qkv_t<QkvTileW8, 2>(Wqkv, bqkv, wb, w, s, hk);
     else launch_qkv_t<QkvTileW8, 0>(Wqkv, bqkv, wb, w, s, hk);
-    GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3((KVP4 + 63) / 64, w.nseg * H), dim3(1024), 0, s, w.kvpart,
-                   w.kvfin, w.L);
 }
 
-void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook* hk) {
-    const int NT = active_tiles(w.L);
-    GATSSPG_LAUNCH(hk, KID_ATTN_APPLY, s, attn_apply_kernel, dim3(NT * H), dim3(256), 0, s, w.kvfin, w.Q, w.MSG, w.L, cross);
+void launch_kv_final(const float* W0, const Workspace& w, int cross, const float* kv_src, hipStream_t s, ProfileHook* hk) {
+    static const int abl = tuning_knob("KVF_ABL", 0);   // tuning builds: timing-only ablations of the operator phase
+    GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3(KVF_BLOCKS, w.nseg * H), dim3(1024), 0, s, w.kvpart, kv_src, w.kvfin,
+                   W0, w.Mop, w.Mpl, w.ksumT, w.L, cross, w.prec, abl);
 }
 
 template <class T, int ABL, int PREC>
@@ -801,9 +852,9 @@ static void launch_mlp0_t(const float* W0, const float* b0, const unsigned short
     allow_big_lds<mlp0_kernel<T, ABL, PREC>>();
     const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
     GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_kernel<T, ABL, PREC>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
-                   (smem_bytes<T, PREC>()), s, W0, b0, wb ? wb + AttnWB::W0_HI : nullptr, wb ? wb + AttnWB::W0_LO : nullptr,
-                   wb ? wb + AttnWB::W0_LO2 : nullptr, w.Z,
-                   w.MSG, w.U, w.statpart, w.L, g_trace);
+                   (smem_bytes<T, PREC>() + sizeof(float) * AttnFoldHooks::ZP_FLOATS), s, W0, b0, wb ? wb + AttnWB::W0_HI : nullptr,
+                   wb ? wb + AttnWB::W0_LO : nullptr, wb ? wb + AttnWB::W0_LO2 : nullptr, w.Z, w.Q, w.Mop, w.Mpl, w.ksumT, w.U,
+                   w.statpart, w.L, g_trace);
 }
 template <class T, int ABL, int PREC>
 static void launch_mlp3_t(const float* W3, const float* b3, const unsigned short* wb, const Workspace& w, hipStream_t s,
@@ -820,22 +871,16 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
                 hipStream_t s, ProfileHook* hk) {
     // MLP0_TILE / MLP3_TILE / MLP0_BTILE select the alternative (equally correct) tile shapes in tuning builds; the ablation
     // variants (wrong results, timing only) exist only in a -DGATSSPG_PROFILING_BUILD library.
-    static const int t0 = tuning_knob("MLP0_TILE", 0), t3 = tuning_knob("MLP3_TILE", 1), tb0 = tuning_knob("MLP0_BTILE", 0);
+    static const int t0 = tuning_knob("MLP0_TILE", 0), t3 = tuning_knob("MLP3_TILE", 1);
     (void)t0;
-    if (w.prec == 1) {
-        if (tb0 == 1) launch_mlp0_t<Mlp0TileB8, 0, 1>(W0, b0, wb, w, s, hk);
-        else launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, wb, w, s, hk);
-    } else if (w.prec == 2) {
-        if (tb0 == 1) launch_mlp0_t<Mlp0TileB8, 0, 2>(W0, b0, wb, w, s, hk);
-        else launch_mlp0_t<Mlp0TileW8, 0, 2>(W0, b0, wb, w, s, hk);
-    }
+    if (w.prec == 1) launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, wb, w, s, hk);
+    else if (w.prec == 2) launch_mlp0_t<Mlp0TileW8, 0, 2>(W0, b0, wb, w, s, hk);
 #ifdef GATSSPG_PROFILING_BUILD
     else if (t0 == 11) launch_mlp0_t<Mlp0TileW8, 1, 0>(W0, b0, wb, w, s, hk);   // no global loads in the loop
     else if (t0 == 12) launch_mlp0_t<Mlp0TileW8, 2, 0>(W0, b0, wb, w, s, hk);   // no loads, no LDS writes
     else if (t0 == 15) launch_mlp0_t<Mlp0TileW8, 5, 0>(W0, b0, wb, w, s, hk);   // all workgroups stream the same (cache-hot) panels
     else if (t0 == 16) launch_mlp0_t<Mlp0TileW8, 6, 0>(W0, b0, wb, w, s, hk);   // every load L1-hot
 #endif
-    else if (t0 == 2) launch_mlp0_t<Mlp0TileW16, 0, 0>(W0, b0, wb, w, s, hk);
     else launch_mlp0_t<Mlp0TileW8, 0, 0>(W0, b0, wb, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
     if (w.prec == 1 && t3 == 0) launch_mlp3_t<Mlp3Tile, 0, 1>(W3, b3, wb, w, s, hk);

@@ -6,7 +6,7 @@ namespace gatsspg {
 
 // Kernel ids (also the `kernel_id` of gatsspg_forward_profiled, include/gatsspg.h)
 enum KernelId {
-    KID_LOAD_STATE = 0, KID_GATS = 1, KID_QKV_KV = 2, KID_KV_FINAL = 3, KID_ATTN_APPLY = 4, KID_MLP0 = 5,
+    KID_LOAD_STATE = 0, KID_GATS = 1, KID_QKV_KV = 2, KID_KV_FINAL = 3, KID_ATTN_APPLY = 4 /* retired: folded into kv_final + mlp0 */, KID_MLP0 = 5,
     KID_STAT_FINAL = 6, KID_MLP3 = 7, KID_FINAL_PROJ = 8, KID_SCORE_EXP = 9, KID_CONF_FINALIZE = 10,
     KID_MATCH_TAIL = 11, KID_GATS_WLT = 12, KID_SOFTMAX_STATS = 13, KID_COUNT = 14
 };
@@ -45,7 +45,10 @@ extern unsigned long long* g_trace;  // per-workgroup timeline buffer of mlp0_ke
 // packedb: the split-bf16 weight planes of this layer (AttnWB offsets), used when w.prec == 1
 void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* packedb, const Workspace& w, hipStream_t s,
                    ProfileHook* hk = nullptr);
-void launch_attn_apply(const Workspace& w, int cross, hipStream_t s, ProfileHook* hk = nullptr);
+// KV / ksum sums of every active SOURCE segment + the message operators M_t of their TARGET segments (cross: the other side of
+// the frame) for mlp.0.  W0: the layer's packed mlp.0 operator [512][512].  kv_src: nullptr, or (amortised mode) the cached final
+// KV sums [b][4][KVP] of the 3D-side sources, used instead of the partials.
+void launch_kv_final(const float* W0, const Workspace& w, int cross, const float* kv_src, hipStream_t s, ProfileHook* hk = nullptr);
 void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const unsigned short* packedb,
                 const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);

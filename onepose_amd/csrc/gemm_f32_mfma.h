@@ -77,15 +77,78 @@ __device__ __forceinline__ vf4 ldg4u_off(const float* base, unsigned byte_off) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Main-loop hooks of the mlp.0 kernel with the linear-attention apply folded in (GATs_SuperGlue.py:78-79,101,113,122):
+//   u = W0a x + sum_h z_h (.) (M_h Qf_h) + b,   M_h = (W0b Wm)[:, head h] KV_h  (kv_final_kernel),   Qf = elu(q) + 1,
+//   z_h[n] = 1 / (sum_d Qf_h[d][n] ksum_h[d] + 1e-6).
+// The K loop runs over [x ; Qf] (16 slabs of 32): slabs 0..7 accumulate the x part, slabs 8 + 2h, 9 + 2h the product of
+// head h into a zeroed accumulator, which is folded into the kept sum with the per-column z_h (a per-lane scalar in the
+// 32x32 MFMA C layout) when the pair ends.  The denominators come from the staged Qf values themselves: every thread
+// multiplies the 4 consecutive k rows of ONE column it sees (fp32 loop: from the LDS slab being computed; split-bf16
+// loops: the registers it is about to split) with the source's ksum, the two slabs of a head are added in the thread, the
+// eight per-wave partials go to LDS and are summed in wave order at the fold: fixed order, no atomics.
+// Requires a 64-column tile on 8 waves (thread = (k group = wave, column = lane)) and one 32x32 MFMA tile per wave.
+// ---------------------------------------------------------------------------------------------------------------------
+struct NoHooks {
+    static constexpr bool ENABLED = false;
+};
+struct AttnFoldHooks {
+    static constexpr bool ENABLED = true;
+    static constexpr int SPLIT = 8;          // first slab of the head phase
+    static constexpr int ZP_FLOATS = 2 * 8 * 64;
+    const float* ks;                         // ksum of the source segment, [4][64] (global, wave-uniform reads)
+    float* zp;                               // LDS [2 (head parity)][8 waves][64 columns]
+    f32x16 kept;                             // x part + folded heads
+    float carry;                             // this thread's partial of the first slab of the current head
+    int wave, lane, col;                     // col = this lane's column in the MFMA C layout (wn * 32 + l31)
+    __device__ __forceinline__ void init(const float* ksum_src, float* zp_lds, int wn) {
+        ks = ksum_src; zp = zp_lds; carry = 0.f;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        lane = threadIdx.x & 63;
+        col = wn * 32 + (lane & 31);
+    }
+    // j = slab index within the head phase (0..7); v0..v3 = rows 4 * wave .. + 3 of that slab, column `lane` of the tile
+    __device__ __forceinline__ void partial(int j, float v0, float v1, float v2, float v3) {
+        const int h = j >> 1;
+        const float* k = ks + h * 64 + (j & 1) * 32 + wave * 4;
+        float p = v0 * k[0];
+        p = fmaf(v1, k[1], p);
+        p = fmaf(v2, k[2], p);
+        p = fmaf(v3, k[3], p);
+        if (j & 1) zp[((h & 1) * 8 + wave) * 64 + lane] = carry + p;
+        else carry = p;
+    }
+    // called after the barrier that ends the slab pair (i, i + 1)
+    __device__ __forceinline__ void pair_end(int i, f32x16& acc) {
+        if (i < SPLIT - 2) return;
+        if (i == SPLIT - 2) {
+            kept = acc;
+        } else {
+            const int h = (i - SPLIT) >> 1;
+            const float* zr = zp + (h & 1) * 8 * 64 + col;
+            float d = zr[0];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) d += zr[w * 64];
+            const float z = 1.f / (d + 1e-6f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kept[r] = fmaf(z, acc[r], kept[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
+};
+
 // ABLATE (profiling only, wrong results): 1 = no global loads in the steady-state loop,
 //   2 = no global loads and no LDS writes, 3 = steady-state loop cut to one step pair,
 //   6 = every load of a wave hits the same 1 KiB (always L1-hot)
 template <class T, class ASlab, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, int ABLATE = 0,
-          class BCol = IdentityCol>
+          class BCol = IdentityCol, class Hooks = NoHooks>
 __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
                                                  BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform,
-                                                 BCol bcol = BCol()) {
+                                                 BCol bcol = BCol(), Hooks* hooks = nullptr) {
     constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN;
+    if constexpr (Hooks::ENABLED)
+        static_assert(BN == 64 && T::THREADS == 512 && TM == 1 && TN == 1 && !T::AKM, "fold hooks: 64-column tile, 8 waves, one MFMA tile per wave");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -187,7 +250,7 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     };
     // One step: compute slab from `cur`; start the global loads of the slab three steps ahead into the
     // register set just freed; write the slab one step ahead (registers filled two steps ago) into `nxt`.
-    auto step = [&](const float* cur, float* nxt, int kt_load, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC],
+    auto step = [&](const float* cur, float* nxt, int kt_cur, int kt_load, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC],
                     float2(&rx)[T::B_VEC]) {
         float a0[TM][8], b0[TN][8], a1[TM][8], b1[TN][8];
         // Eight MFMA groups (2 k-steps each) with the memory work of the step placed between them (a 32x32x2
@@ -202,6 +265,12 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
         mfma4(a0, b0, 0, 2);
         __builtin_amdgcn_sched_barrier(0);
         read_frags(cur, 1, a1, b1);                               // gap 1
+        if constexpr (Hooks::ENABLED) {
+            if (kt_cur >= Hooks::SPLIT) {                         // denominators of the folded linear attention (block-uniform)
+                const float* bq = cur + T::A_FLOATS + hooks->wave * 4 * BN + hooks->lane;
+                hooks->partial(kt_cur - Hooks::SPLIT, bq[0], bq[BN], bq[2 * BN], bq[3 * BN]);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         mfma4(a0, b0, 2, 2);
         __builtin_amdgcn_sched_barrier(0);
@@ -243,10 +312,11 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     // statically indexed (hipcc would otherwise sink the loads into a conditional block next to their use).
     const int KTL = ABLATE == 3 ? 2 : KT;
     for (int i = 0; i < KTL; i += 2) {
-        step(buf0, buf1, min(i + 3, last), ra0, rb0, rx0);
+        step(buf0, buf1, i, min(i + 3, last), ra0, rb0, rx0);
         __syncthreads();
-        step(buf1, buf0, min(i + 4, last), ra1, rb1, rx1);
+        step(buf1, buf0, i + 1, min(i + 4, last), ra1, rb1, rx1);
         __syncthreads();
+        if constexpr (Hooks::ENABLED) hooks->pair_end(i, acc[0][0]);
     }
 }
 
@@ -298,11 +368,14 @@ struct Bf3Layout {
 // a_hi(kt) / a_lo(kt): bf16 plane pointers of A slab kt (&A[row0][kt*32], row stride lda elements).
 // b_slab(kt): fp32 pointer &B[kt*32][col0], row stride ldb.  x_mean / x_rstd / bxform: per-k-row aux values applied to
 // the B values before the split (mlp.3: InstanceNorm + ReLU on the operand load).
-template <class T, class AHi, class ALo, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX>
+template <class T, class AHi, class ALo, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, class Hooks = NoHooks>
 __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, AHi a_hi, ALo a_lo,
-                                                     int lda, BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform) {
+                                                     int lda, BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform,
+                                                     Hooks* hooks = nullptr) {
     static_assert(!T::AKM && !T::BU, "row-major A, aligned B");
     using LY = Bf3Layout<T>;
+    if constexpr (Hooks::ENABLED)
+        static_assert(T::BN == 64 && T::THREADS == 512 && T::TM == 1 && T::TN == 1 && LY::KPT == 4, "fold hooks: 64-column tile, 8 waves");
     constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN, KS = LY::KS, AP = LY::A_PIECES, KPT = LY::KPT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN;
@@ -342,7 +415,11 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
             if constexpr (HAS_AUX) rx[j] = make_float2(x_mean(kt)[k0 + j], x_rstd(kt)[k0 + j]);
         }
     };
-    auto swrite = [&](unsigned short* stage, const u32x4(&ra)[AP], const float(&rb)[KPT], const float2(&rx)[KPT]) {
+    // kw: index of the slab being written (fold hooks: its Qf values enter the denominators before they are split)
+    auto swrite = [&](unsigned short* stage, int kw, const u32x4(&ra)[AP], const float(&rb)[KPT], const float2(&rx)[KPT]) {
+        if constexpr (Hooks::ENABLED) {
+            if (kw >= Hooks::SPLIT && kw < KT) hooks->partial(kw - Hooks::SPLIT, rb[0], rb[1], rb[2], rb[3]);
+        }
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             const bool lo = (p * T::THREADS) / (BM * 4) != 0;
@@ -408,22 +485,23 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
     const int last = KT - 1;
     gload(0, ra1, rb1, rx1);              // slab 0 through set 1, slab 1 (set 0) requested together with it (see gemm_mainloop_ex)
     gload(min(1, last), ra0, rb0, rx0);
-    swrite(buf0, ra1, rb1, rx1);
+    swrite(buf0, 0, ra1, rb1, rx1);
     gload(min(2, last), ra1, rb1, rx1);
     __syncthreads();
     // step i: MFMAs of slab i, slab i+1 (in registers since step i-2) is split and written to the free buffer, the freed
     // registers start loading slab i+3
     for (int i = 0; i < KT; i += 2) {
         compute(buf0);
-        swrite(buf1, ra0, rb0, rx0);
+        swrite(buf1, i + 1, ra0, rb0, rx0);
         asm volatile("" ::: "memory");
         gload(min(i + 3, last), ra0, rb0, rx0);
         __syncthreads();
         compute(buf1);
-        swrite(buf0, ra1, rb1, rx1);
+        swrite(buf0, i + 2, ra1, rb1, rx1);
         asm volatile("" ::: "memory");
         gload(min(i + 4, last), ra1, rb1, rx1);
         __syncthreads();
+        if constexpr (Hooks::ENABLED) hooks->pair_end(i, acc[0][0]);
     }
 }
 
@@ -460,11 +538,14 @@ __device__ __forceinline__ int bf6_swz(int row, int chunk) { return chunk ^ ((ro
 
 // a_pl(kt, plane): bf16 plane pointer of A slab kt (&A_plane[row0][kt*32], row stride lda elements); the rest as in
 // gemm_mainloop_bf3_ex.
-template <class T, class APlane, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX>
+template <class T, class APlane, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, class Hooks = NoHooks>
 __device__ __forceinline__ void gemm_mainloop_bf6_ex(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, APlane a_pl, int lda,
-                                                     BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform) {
+                                                     BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform,
+                                                     Hooks* hooks = nullptr) {
     static_assert(!T::AKM && !T::BU, "row-major A, aligned B");
     using LY = Bf6Layout<T>;
+    if constexpr (Hooks::ENABLED)
+        static_assert(T::BN == 64 && T::THREADS == 512 && T::TM == 1 && T::TN == 1 && LY::KPT == 4, "fold hooks: 64-column tile, 8 waves");
     constexpr int BM = T::BM, BN = T::BN, TM = T::TM, TN = T::TN, KS = LY::KS, AP = LY::A_PIECES, KPT = LY::KPT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN;
@@ -501,7 +582,10 @@ __device__ __forceinline__ void gemm_mainloop_bf6_ex(f32x16 (&acc)[T::TM][T::TN]
             if constexpr (HAS_AUX) rx[j] = make_float2(x_mean(kt)[k0 + j], x_rstd(kt)[k0 + j]);
         }
     };
-    auto swrite = [&](unsigned short* stage, const u32x4(&ra)[AP], const float(&rb)[KPT], const float2(&rx)[KPT]) {
+    auto swrite = [&](unsigned short* stage, int kw, const u32x4(&ra)[AP], const float(&rb)[KPT], const float2(&rx)[KPT]) {
+        if constexpr (Hooks::ENABLED) {
+            if (kw >= Hooks::SPLIT && kw < KT) hooks->partial(kw - Hooks::SPLIT, rb[0], rb[1], rb[2], rb[3]);
+        }
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             const int plane = (p * T::THREADS) / (BM * 4);
@@ -579,15 +663,31 @@ __device__ __forceinline__ void gemm_mainloop_bf6_ex(f32x16 (&acc)[T::TM][T::TN]
     // of slab i+3.  (Placing the second-step reads, the LDS writes and the loads BETWEEN the MFMA pairs, as the fp32 loop does,
     // was measured on this loop: mlp0 34.9 vs 32.5 us, 1337 vs 1435 frames/s -- the bf16 MFMAs are too short to hide them;
     // write + loads BEFORE the MFMAs: 1137 frames/s -- the write then waits for loads that have had one step, not two, to land.)
-    auto step = [&](const unsigned short* cur, unsigned short* nxt, int kt_load, u32x4(&ra)[AP], float(&rb)[KPT], float2(&rx)[KPT]) {
-        bf16x8 af0[3][TM], bf0[3][TN], af1[3][TM], bf1[3][TN];
-        read_frags(cur, 0, af0, bf0);
-        read_frags(cur, 1, af1, bf1);
+    auto step = [&](const unsigned short* cur, unsigned short* nxt, int kw, int kt_load, u32x4(&ra)[AP], float(&rb)[KPT], float2(&rx)[KPT]) {
+        bool two_reads = false;
+        if constexpr (Hooks::ENABLED) two_reads = kw > Hooks::SPLIT;   // the slab being computed (kw - 1) belongs to the head phase
+        if (two_reads) {
+            // head phase of the attention fold: a second accumulator (16 registers) is alive, so the fragments of the second
+            // k16 step re-use the registers of the first (read -> 6 MFMAs -> read -> 6 MFMAs) instead of being fetched up front
+            // -- the 128-VGPR budget of two workgroups per CU has no room for both (spilled 28 registers: mlp0 29.6 -> 36.9 us)
+            bf16x8 af[3][TM], bf[3][TN];
+            read_frags(cur, 0, af, bf);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) mfma_pair(af0, bf0, g);
+            for (int g = 0; g < 3; ++g) mfma_pair(af, bf, g);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(cur, 1, af, bf);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) mfma_pair(af1, bf1, g);
-        swrite(nxt, ra, rb, rx);
+            for (int g = 0; g < 3; ++g) mfma_pair(af, bf, g);
+        } else {
+            bf16x8 af0[3][TM], bf0[3][TN], af1[3][TM], bf1[3][TN];
+            read_frags(cur, 0, af0, bf0);
+            read_frags(cur, 1, af1, bf1);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) mfma_pair(af0, bf0, g);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) mfma_pair(af1, bf1, g);
+        }
+        swrite(nxt, kw, ra, rb, rx);
         asm volatile("" ::: "memory");
         gload_a(kt_load, ra);
         gload_b(kt_load, rb, rx);
@@ -597,43 +697,44 @@ __device__ __forceinline__ void gemm_mainloop_bf6_ex(f32x16 (&acc)[T::TM][T::TN]
     const int last = KT - 1;
     gload(0, ra1, rb1, rx1);
     gload(min(1, last), ra0, rb0, rx0);
-    swrite(buf0, ra1, rb1, rx1);
+    swrite(buf0, 0, ra1, rb1, rx1);
     gload(min(2, last), ra1, rb1, rx1);
     __syncthreads();
     for (int i = 0; i < KT; i += 2) {
-        step(buf0, buf1, min(i + 3, last), ra0, rb0, rx0);
+        step(buf0, buf1, i + 1, min(i + 3, last), ra0, rb0, rx0);
         __syncthreads();
-        step(buf1, buf0, min(i + 4, last), ra1, rb1, rx1);
+        step(buf1, buf0, i + 2, min(i + 4, last), ra1, rb1, rx1);
         __syncthreads();
+        if constexpr (Hooks::ENABLED) hooks->pair_end(i, acc[0][0]);
     }
 }
 
 struct NoXform1 {
     __device__ __forceinline__ float operator()(float v, float2) const { return v; }
 };
-template <class T, class AHi, class ALo, class BSlab>
+template <class T, class AHi, class ALo, class BSlab, class Hooks = NoHooks>
 __device__ __forceinline__ void gemm_mainloop_bf3(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, AHi a_hi, ALo a_lo,
-                                                  int lda, BSlab b_slab, int ldb) {
+                                                  int lda, BSlab b_slab, int ldb, Hooks* hooks = nullptr) {
     auto nox = [](int) { return static_cast<const float*>(nullptr); };
-    gemm_mainloop_bf3_ex<T, AHi, ALo, BSlab, decltype(nox), decltype(nox), NoXform1, false>(acc, smem, KT, a_hi, a_lo, lda, b_slab,
-                                                                                          ldb, nox, nox, NoXform1());
+    gemm_mainloop_bf3_ex<T, AHi, ALo, BSlab, decltype(nox), decltype(nox), NoXform1, false, Hooks>(acc, smem, KT, a_hi, a_lo, lda, b_slab,
+                                                                                                 ldb, nox, nox, NoXform1(), hooks);
 }
 
-template <class T, class APlane, class BSlab>
+template <class T, class APlane, class BSlab, class Hooks = NoHooks>
 __device__ __forceinline__ void gemm_mainloop_bf6(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, APlane a_pl, int lda,
-                                                  BSlab b_slab, int ldb) {
+                                                  BSlab b_slab, int ldb, Hooks* hooks = nullptr) {
     auto nox = [](int) { return static_cast<const float*>(nullptr); };
-    gemm_mainloop_bf6_ex<T, APlane, BSlab, decltype(nox), decltype(nox), NoXform1, false>(acc, smem, KT, a_pl, lda, b_slab, ldb, nox,
-                                                                                        nox, NoXform1());
+    gemm_mainloop_bf6_ex<T, APlane, BSlab, decltype(nox), decltype(nox), NoXform1, false, Hooks>(acc, smem, KT, a_pl, lda, b_slab, ldb, nox,
+                                                                                               nox, NoXform1(), hooks);
 }
 
 // convenience wrapper without per-row aux / transform
-template <class T, class ASlab, class BSlab, int ABLATE = 0, class BCol = IdentityCol>
+template <class T, class ASlab, class BSlab, int ABLATE = 0, class BCol = IdentityCol, class Hooks = NoHooks>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
-                                              BSlab b_slab, int ldb, BCol bcol = BCol()) {
+                                              BSlab b_slab, int ldb, BCol bcol = BCol(), Hooks* hooks = nullptr) {
     auto nox = [](int) { return static_cast<const float*>(nullptr); };
-    gemm_mainloop_ex<T, ASlab, BSlab, decltype(nox), decltype(nox), NoXform, false, ABLATE, BCol>(
-        acc, smem, KT, a_slab, lda, b_slab, ldb, nox, nox, NoXform(), bcol);
+    gemm_mainloop_ex<T, ASlab, BSlab, decltype(nox), decltype(nox), NoXform, false, ABLATE, BCol, Hooks>(
+        acc, smem, KT, a_slab, lda, b_slab, ldb, nox, nox, NoXform(), bcol, hooks);
 }
 
 // Epilogue helper: the accumulator tile leaves through LDS as 16-byte stores (16 lanes cover one 256-byte row segment
