@@ -615,6 +615,9 @@ def main():
     ap.add_argument("--config", default="headline", choices=list(CONFIGS),
                     help="workload: 'headline' = BASELINE configs[1] (the value the driver records); the others are "
                          "separately reported lines (config.workload names them)")
+    ap.add_argument("--shape", default=None, metavar="N1,N2[,B]",
+                    help="tuning runs: override the workload's N_2D, N_3D (and frames per step); the line is labelled, carries no "
+                         "reference parity number and is never a headline number")
     ap.add_argument("--amortised", action="store_true",
                     help="also report the database-cache mode (query-independent part of the first 3 GNN layers "
                          "precomputed once per object); informative, never the headline value")
@@ -659,6 +662,10 @@ def main():
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus})")
     rank, local_rank, world = sharding.init_process_group(backend="gloo" if args.dry_run else None)
     cfg = CONFIGS[args.config]
+    if args.shape:
+        dims = [int(v) for v in args.shape.split(",")]
+        cfg = dict(cfg, n1=dims[0], n2=dims[1], b=dims[2] if len(dims) > 2 else cfg["b"], golden=None,
+                   what=f"CUSTOM SHAPE (tuning run, not a BASELINE config): N_2D={dims[0]} N_3D={dims[1]}, arithmetic of '{args.config}'")
     K, W, S, R = args.steps, args.warmup, max(1, args.streams), max(1, args.reps)
 
     if args.dry_run:
@@ -745,7 +752,7 @@ def main():
     # point, one flags bit.  bf16x6 is fp32-class (operands split exactly into three bf16 planes); bf16x3 drops to ~2^-16.
     side = None
     # (a multi-rank job skips them: ranks 1..N-1 would sit in the metrics all_gather while rank 0 runs two untimed passes)
-    if rank == 0 and world == 1 and args.config == "headline" and not args.no_side_arithmetics:
+    if rank == 0 and world == 1 and args.config == "headline" and not args.shape and not args.no_side_arithmetics:
         side = {p: side_arithmetic(device, cfg, p, base.shared_inputs, K, W, S) for p in ("bf16x6", "bf16x3")}
 
     amortised = None
@@ -807,7 +814,7 @@ def main():
                        "end_to_end_single_stream_f32_mfma_frac": round(falg * bsz / latency / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "kernel": args.kernel + "_kernel", "achieved": round(achieved, 2),
                          "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": pmc_traffic(args.kernel) if args.config == "headline" else None,
+                         "traffic": pmc_traffic(args.kernel) if args.config == "headline" and not args.shape else None,
                          "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 PMC passes of this build committed under "
                                            "profiles/, not measured in this run)" if args.config == "headline" else None,
                          "kernel_ms": round(kern_ms, 5), "empty_event_pair_ms": round(pair_ms, 5), "flops_per_launch": fl,

@@ -280,6 +280,7 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
     const int c = h * DH + 4 * db;   // first of this block's 4 columns of M_t
     if (prec == 0) {
         vf4 v = {o0, o1, o2, o3};
+        // (write-through / non-temporal forms of this store -- sc1, sc0 sc1, nt -- were A/B-timed: no difference)
         *reinterpret_cast<vf4*>(mop_seg(Mop, tseg) + (size_t)row * MOP_LD + c) = v;
     } else {
         // split planes in the slab-major layout of the weight planes: (m, k) at ((k / 32) * 512 + m) * 32 + k % 32
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
 // =====================================================================================================
 // tiles (one InstanceNorm partial per 64-column tile whatever BN is)
 using Mlp0TileW8 = GemmTile<128, MLP0_BN, 4, 2, false>;       // all arithmetics: 8 waves, one 32x32 MFMA tile each (fp32: 43.1 vs 45.0 us on 4 waves)
+using Mlp0TileS = GemmTile<64, MLP0_BN, 2, 2, false, false, 2>;   // fp32, launches that leave CUs empty: 64x64, two K groups of 4 waves
 // (round 2 also measured 128x128 tiles -- 16 waves fp32: kernel -3 %, frames/s in flight -0.8 %; 8 waves split-bf16: kernel -4 %,
 //  frames/s equal; the attention fold needs thread = (k group, column) on a 64-column tile, they are gone)
 
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp0_kernel(c
     ct = global_tile(L, ct * TPW) / TPW;   // windows and segments are multiples of 128 columns
     const int c0 = ct * T::BN, ld = L.ld;
     const float* A = W0 + (size_t)rt * T::BM * 512;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % T::WAVES_MN;   // (K-split tiles: wave within its group)
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
     // requested before the main loop (see qkv_kv_kernel); the six-term loop has no 16 registers to park it in (128-VGPR budget of
     // two 8-wave workgroups per CU) and fetches it after the loop
@@ -386,6 +388,7 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp0_kernel(c
                                                                                                       IdentityCol(), &hooks);
     }
     acc[0][0] = hooks.kept;
+    ksplit_reduce<T>(acc, smem);
     if constexpr (PREC == 2) load_bias();
     const unsigned long long t_loop = trace ? wall_clock64() : 0;
     constexpr int TS = T::BN + 1;
@@ -513,6 +516,7 @@ __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restric
 // =====================================================================================================
 using Mlp3TileTallW8 = GemmTile<128, 64, 4, 2, false>;   // both arithmetics: 128x64 on 8 waves, 252 workgroups (fp32: 21.3 vs 24.6 us, 938 vs 914 frames/s one at a time)
 using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;          // alternative (tuning builds): 64x64 on 4 waves, 504 workgroups
+using Mlp3TileS = GemmTile<64, 64, 2, 2, false, false, 2>;   // fp32, launches that leave CUs empty: 64x64, two K groups of 4 waves
 
 template <class T, int ABL = 0, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
@@ -535,7 +539,8 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp3_kernel(c
     // start from the residual + bias: the Z tile is fetched before the main loop instead of after it
     // (its latency hides under the GEMM; the epilogue becomes a pure store)
     {
-        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+        const int lane_ = threadIdx.x & 63, wave_ = (threadIdx.x >> 6) % T::WAVES_MN;
+        const bool first_group = (int)(threadIdx.x >> 6) < T::WAVES_MN;   // K-split tiles: the second wave group starts from zero
         const int wm_ = wave_ / T::WN, wn_ = wave_ % T::WN, half_ = lane_ >> 5, l31_ = lane_ & 31;
 #pragma unroll
         for (int tm = 0; tm < T::TM; ++tm)
@@ -544,7 +549,8 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp3_kernel(c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rt * T::BM + (wm_ * T::TM + tm) * 32 + mfma_row(r, half_);
-                    acc[tm][tn][r] = Z[(size_t)row * ld + c0 + (wn_ * T::TN + tn) * 32 + l31_] + b3[row];
+                    const float v = Z[(size_t)row * ld + c0 + (wn_ * T::TN + tn) * 32 + l31_] + b3[row];
+                    acc[tm][tn][r] = first_group ? v : 0.f;
                 }
     }
     auto al = [&](int kt) { return A + kt * BK; };
@@ -572,6 +578,7 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp3_kernel(c
         gemm_mainloop_ex<T, decltype(al), decltype(bl), decltype(xm), decltype(xr), decltype(bx), true, ABL>(
             acc, smem, 512 / BK, al, 512, bl, ld, xm, xr, bx);
     }
+    ksplit_reduce<T>(acc, smem);
     store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [](int, float v) { return v; });
 }
 
@@ -872,8 +879,14 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     // MLP0_TILE / MLP3_TILE / MLP0_BTILE select the alternative (equally correct) tile shapes in tuning builds; the ablation
     // variants (wrong results, timing only) exist only in a -DGATSSPG_PROFILING_BUILD library.
     static const int t0 = tuning_knob("MLP0_TILE", 0), t3 = tuning_knob("MLP3_TILE", 1);
+    // Launches that leave CUs empty (few columns: OnePose's own 500 x 2000 operating point) are bound by ONE workgroup's
+    // dependent MFMA chain, not by the matrix pipes: they take the 64x64 tile with the K loop split over two wave groups
+    // (4x / 2x the workgroups, half the chain per wave).  SMALL_NT = largest number of 64-column tiles that still does.
+    static const int small_nt0 = tuning_knob("SMALL_NT0", 0), small_nt3 = tuning_knob("SMALL_NT3", 64);
+    const bool small0 = w.prec == 0 && active_tiles(w.L) <= small_nt0, small3 = w.prec == 0 && active_tiles(w.L) <= small_nt3;
     (void)t0;
-    if (w.prec == 1) launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, wb, w, s, hk);
+    if (small0 && t0 == 0) launch_mlp0_t<Mlp0TileS, 0, 0>(W0, b0, wb, w, s, hk);
+    else if (w.prec == 1) launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, wb, w, s, hk);
     else if (w.prec == 2) launch_mlp0_t<Mlp0TileW8, 0, 2>(W0, b0, wb, w, s, hk);
 #ifdef GATSSPG_PROFILING_BUILD
     else if (t0 == 11) launch_mlp0_t<Mlp0TileW8, 1, 0>(W0, b0, wb, w, s, hk);   // no global loads in the loop
@@ -883,7 +896,8 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
 #endif
     else launch_mlp0_t<Mlp0TileW8, 0, 0>(W0, b0, wb, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
-    if (w.prec == 1 && t3 == 0) launch_mlp3_t<Mlp3Tile, 0, 1>(W3, b3, wb, w, s, hk);
+    if (small3 && t3 == 1) launch_mlp3_t<Mlp3TileS, 0, 0>(W3, b3, wb, w, s, hk);
+    else if (w.prec == 1 && t3 == 0) launch_mlp3_t<Mlp3Tile, 0, 1>(W3, b3, wb, w, s, hk);
     else if (w.prec == 1) launch_mlp3_t<Mlp3TileTallW8, 0, 1>(W3, b3, wb, w, s, hk);
     else if (w.prec == 2) launch_mlp3_t<Mlp3TileTallW8, 0, 2>(W3, b3, wb, w, s, hk);
 #ifdef GATSSPG_PROFILING_BUILD

@@ -28,9 +28,13 @@ typedef vf4 vf4u __attribute__((aligned(4)));
 
 // BU_: the B slab pointers are only 4-byte aligned (column-shifted views of an activation plane, used by the
 // 3x3 convolutions of the SuperPoint extractor)
-template <int BM_, int BN_, int WM_, int WN_, bool AKM_, bool BU_ = false>
+// KS_: intra-workgroup K split (fp32 loop only).  KS = 2 doubles the waves of a workgroup: wave group kg = wave / (WM * WN)
+// multiplies the kg-th half of every 32-deep slab (16 of its 32 k) into its own accumulators, ksplit_reduce() adds the groups
+// at the end.  Same tile, same staging, half the MFMA chain per wave -- for launches that leave CUs empty (small N), where a
+// lone workgroup's time is its waves' dependent MFMA chain, not the matrix pipe.
+template <int BM_, int BN_, int WM_, int WN_, bool AKM_, bool BU_ = false, int KS_ = 1>
 struct GemmTile {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, KS = KS_;
     static constexpr bool AKM = AKM_, BU = BU_;
     static constexpr int TM = BM / WM / 32;   // 32x32 MFMA tiles per wave along M
     static constexpr int TN = BN / WN / 32;   // ... along N
@@ -39,13 +43,15 @@ struct GemmTile {
     static constexpr int B_FLOATS = BK * BN;
     static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
     static constexpr int SMEM_FLOATS = 2 * STAGE_FLOATS;
-    static constexpr int THREADS = 64 * WM * WN;       // 4, 8 or 16 waves
+    static constexpr int WAVES_MN = WM * WN;           // waves that tile the output; x KS wave groups
+    static constexpr int THREADS = 64 * WM * WN * KS;  // 4, 8 or 16 waves
     static constexpr int A_VEC = BM * BK / 4 / THREADS;   // float4 per thread per slab
     static constexpr int B_PIECES = BK * BN / 4;          // float4 pieces of a B slab
     // a narrow tile on many waves has fewer B pieces than threads: every thread still moves one piece, the surplus threads
     // duplicate the piece of thread (tid mod B_PIECES) -- same bytes to the same LDS address, no guarded loads
     static constexpr int B_VEC = B_PIECES >= THREADS ? B_PIECES / THREADS : 1;
-    static_assert(WM * WN == 4 || WM * WN == 8 || WM * WN == 16, "workgroup = 4, 8 or 16 waves");
+    static_assert(WM * WN * KS == 4 || WM * WN * KS == 8 || WM * WN * KS == 16, "workgroup = 4, 8 or 16 waves");
+    static_assert(KS == 1 || KS == 2, "K split: one or two wave groups");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
     static_assert(A_VEC >= 1 && (B_PIECES % THREADS == 0 || THREADS % B_PIECES == 0), "tile / workgroup mismatch");
 };
@@ -152,8 +158,10 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / T::WN, wn = wave % T::WN;
+    const int kg = wave / T::WAVES_MN, wq = wave % T::WAVES_MN;   // K-split group, wave within the output tiling
+    const int wm = wq / T::WN, wn = wq % T::WN;
     const int half = lane >> 5, l31 = lane & 31;
+    static_assert(T::KS == 1 || (ABLATE == 0 && !T::AKM), "K split: plain row-major fp32 loop only");
 
     // loop-invariant per-thread byte offsets (global) and LDS float offsets of the staging slots
     unsigned a_goff[T::A_VEC], b_goff[T::B_VEC], x_goff[T::B_VEC];
@@ -292,6 +300,34 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
         }
     };
 
+    // K-split step (T::KS == 2): this wave group's half of the slab (8 k-steps per lane half = 8 MFMAs per 32x32 tile), the
+    // memory work of the step between the four MFMA pairs
+    auto step_ks = [&](const float* cur, float* nxt, int kt_cur, int kt_load, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC],
+                       float2(&rx)[T::B_VEC]) {
+        float a0[TM][8], b0[TN][8];
+        read_frags(cur, kg, a0, b0);
+        if constexpr (Hooks::ENABLED) {
+            if (kt_cur >= Hooks::SPLIT) {
+                const float* bq = cur + T::A_FLOATS + hooks->wave * 4 * BN + hooks->lane;
+                hooks->partial(kt_cur - Hooks::SPLIT, bq[0], bq[BN], bq[2 * BN], bq[3 * BN]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(a0, b0, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        swrite(nxt, ra, rb, rx);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            mfma4(a0, b0, 2 + 2 * g, 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q)
+                if (q % 3 == g) gload_piece(kt_load, q, ra, rb, rx);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     // Pipeline (prefetch distance 2).  During step i the LDS buffer (i+1)&1 is free (every wave passed the
     // barrier that ended step i-1), so slab i+1 -- sitting in register set i&1 since step i-2 -- is written
     // there while slab i is computed from buffer i&1, and the freed registers start loading slab i+3.
@@ -312,11 +348,43 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     // statically indexed (hipcc would otherwise sink the loads into a conditional block next to their use).
     const int KTL = ABLATE == 3 ? 2 : KT;
     for (int i = 0; i < KTL; i += 2) {
-        step(buf0, buf1, i, min(i + 3, last), ra0, rb0, rx0);
+        if constexpr (T::KS == 2) step_ks(buf0, buf1, i, min(i + 3, last), ra0, rb0, rx0);
+        else step(buf0, buf1, i, min(i + 3, last), ra0, rb0, rx0);
         __syncthreads();
-        step(buf1, buf0, i + 1, min(i + 4, last), ra1, rb1, rx1);
+        if constexpr (T::KS == 2) step_ks(buf1, buf0, i + 1, min(i + 4, last), ra1, rb1, rx1);
+        else step(buf1, buf0, i + 1, min(i + 4, last), ra1, rb1, rx1);
         __syncthreads();
         if constexpr (Hooks::ENABLED) hooks->pair_end(i, acc[0][0]);
+    }
+}
+
+// K split: add the accumulators of the wave groups (after the main loop, whose last barrier freed `smem`).  Every group ends
+// with the full sums (group 0's value + group 1's value on both), so the epilogues need not know about the split: the waves
+// of group 1 redo group 0's epilogue stores with identical values.  smem must hold THREADS * 16 floats per 32x32 tile.
+template <class T>
+__device__ __forceinline__ void ksplit_reduce(f32x16 (&acc)[T::TM][T::TN], float* smem) {
+    if constexpr (T::KS == 2) {
+        static_assert(T::TM * T::TN * T::THREADS * 16 <= T::SMEM_FLOATS, "the partial accumulators must fit the operand buffers");
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int kg = wave / T::WAVES_MN, wq = wave % T::WAVES_MN;
+#pragma unroll
+        for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    smem[((((kg * T::WAVES_MN + wq) * T::TM + tm) * T::TN + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
+        __syncthreads();
+#pragma unroll
+        for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float o = smem[(((((kg ^ 1) * T::WAVES_MN + wq) * T::TM + tm) * T::TN + tn) * 16 + r) * 64 + lane];
+                    acc[tm][tn][r] = kg ? o + acc[tm][tn][r] : acc[tm][tn][r] + o;   // group 0 + group 1 on both
+                }
+        __syncthreads();
     }
 }
 
@@ -745,7 +813,7 @@ template <class T, class F>
 __device__ __forceinline__ void store_tile_via_lds(const f32x16 (&acc)[T::TM][T::TN], float* smem, float* dst, int ld, F f) {
     constexpr int TS = T::BN + 4;
     static_assert(T::BM * TS <= T::SMEM_FLOATS, "staging tile must fit the operand buffers");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % T::WAVES_MN;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
