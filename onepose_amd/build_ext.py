@@ -79,6 +79,22 @@ def build(force=False, remarks=False, verbose=True, profiling=False, tuning=Fals
     return LIB_PATH
 
 
+def asan_runtime():
+    """Path of clang's shared AddressSanitizer runtime (LD_PRELOAD it into the python that loads an ASan build), or None."""
+    import glob
+    cands = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    return cands[-1] if cands else None
+
+
+def build_asan(out_path):
+    """Debug build of the matcher library with AddressSanitizer on the HOST side (argument checking, workspace carve-up, launch
+    plumbing; device code is not instrumented): SURVEY.md section 5 'sanitizers'.  Never loaded by the package -- tests only."""
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address", "-fno-gpu-sanitize",
+           "-shared-libsan", "-o", out_path] + [os.path.join(CSRC, s) for s in SOURCES]
+    subprocess.run(cmd, check=True, cwd=CSRC, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out_path
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, remarks="--remarks" in sys.argv, profiling="--profiling" in sys.argv,
           tuning="--tuning" in sys.argv)
