@@ -20,17 +20,24 @@ def _conv(sd, name, x, relu=True):
     return F.relu(y) if relu else y
 
 
+def _window_max(t, r):
+    """Maximum over the (2r+1) x (2r+1) window around every pixel, as two 1-D passes (rows, then columns) -- the separable form
+    the HIP nms_kernel evaluates in LDS.  Out-of-image neighbours never win (max_pool2d pads with -inf)."""
+    k = 2 * r + 1
+    return F.max_pool2d(F.max_pool2d(t, (1, k), 1, (0, r)), (k, 1), 1, (r, 0))
+
+
 def _nms(scores, r):
+    """Keypoint non-maximum suppression with the semantics of the reference's simple_nms (superpoint.py:47-62): window maxima
+    are kept; twice more, pixels farther than r from every kept pixel compete among themselves and their window maxima join."""
     if r == 0:
         return scores
-    mp = lambda t: F.max_pool2d(t, kernel_size=2 * r + 1, stride=1, padding=r)
-    zeros = torch.zeros_like(scores)
-    mask = scores == mp(scores)
+    keep = scores == _window_max(scores, r)
     for _ in range(2):
-        supp = mp(mask.float()) > 0
-        ss = torch.where(supp, zeros, scores)
-        mask = mask | ((ss == mp(ss)) & ~supp)
-    return torch.where(mask, scores, zeros)
+        near_kept = _window_max(keep.to(scores.dtype), r) > 0
+        rest = scores.masked_fill(near_kept, 0.0)
+        keep = keep | ((rest == _window_max(rest, r)) & ~near_kept)
+    return scores.masked_fill(~keep, 0.0)
 
 
 def forward(sd, image, config=None, align_corners=True):
