@@ -803,6 +803,8 @@ def main():
                        "n_2d": n1, "n_3d": n2, "num_leaf": NUM_LEAF, "batch": bsz, "steps_per_gpu": K, "frames_per_gpu": K * bsz,
                        "frames_in_flight_per_gpu": S * bsz, "timed_pass_repetitions": R,
                        "timed_pass_seconds": [round(t, 5) for t in reps], "reported": "median repetition",
+                       "value_is": f"all frames of a pass / the median of the {R} timed passes; one pass = exactly {K} steps between barrier + "
+                                   f"synchronize pairs ({elapsed * 1e3:.1f} ms here: with the driver's --steps 20 the number rests on {R} passes of ~16 ms)",
                        "single_frame_latency_ms": round(latency * 1e3 / bsz, 4),
                        "single_stream_frames_per_sec": round(bsz / latency, 2),
                        "parallelism": f"weak scaling: every one of the {world} rank(s) runs its own {K} steps on its own GPU, weights and "
