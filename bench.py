@@ -512,6 +512,12 @@ CONFIGS = {
                    what="headline shape (1000/7000, batch 1) with the attention-layer GEMMs on six-term split-bf16 MFMA (operands "
                         "split exactly into 3 bf16 planes, 6 bf16 products per fp32 product: fp32-class arithmetic on the bf16 "
                         "pipe); reported separately, never the headline value"),
+    "fp16x3": dict(b=1, n1=1000, n2=7000, precision="fp16x3", golden="head_rand",
+                   what="headline shape (1000/7000, batch 1) with the attention-layer GEMMs on three-term split-fp16 MFMA (two fp16 terms per "
+                        "operand = 22 significand bits, 3 fp16 products per fp32 product); reported separately, never the headline value"),
+    "fp16x3-b8": dict(b=8, n1=1000, n2=7000, precision="fp16x3", golden="head_b8",
+                      what="BASELINE configs[2] shape, 8 frames of 1000/7000 per step, attention-layer GEMMs on three-term split-fp16 MFMA "
+                           "(the dtype BASELINE configs[3] names, made to meet the parity bar); reported separately, never the headline value"),
     "bf16x6-b8": dict(b=8, n1=1000, n2=7000, precision="bf16x6", golden="head_b8",
                       what="BASELINE configs[2] ('bf16 MFMA, 64 frames sharded 8 per GPU') -- THE configs[2] line: 8 frames of "
                            "1000/7000 per step, attention-layer GEMMs on six-term split-bf16 MFMA (fp32-class: match indices "
@@ -753,7 +759,7 @@ def main():
     side = None
     # (a multi-rank job skips them: ranks 1..N-1 would sit in the metrics all_gather while rank 0 runs two untimed passes)
     if rank == 0 and world == 1 and args.config == "headline" and not args.shape and not args.no_side_arithmetics:
-        side = {p: side_arithmetic(device, cfg, p, base.shared_inputs, K, W, S) for p in ("bf16x6", "bf16x3")}
+        side = {p: side_arithmetic(device, cfg, p, base.shared_inputs, K, W, S) for p in ("bf16x6", "fp16x3", "bf16x3")}
 
     amortised = None
     if args.amortised:
@@ -782,7 +788,7 @@ def main():
 
     if rank == 0:
         n1, n2, bsz = cfg["n1"], cfg["n2"], runner.b
-        nterms = {"fp32": 0, "bf16x3": 3, "bf16x6": 6}[cfg["precision"]]
+        nterms = {"fp32": 0, "bf16x3": 3, "bf16x6": 6, "fp16x3": 3}[cfg["precision"]]
         split = nterms and args.kernel in ("mlp0", "qkv_kv", "mlp3")
         fl = kernel_flops(args.kernel, n1, n2) * bsz
         achieved = fl / (kern_ms * 1e-3) / 1e12
@@ -798,7 +804,7 @@ def main():
             "vs_baseline": None, "dtype": "f32" if cfg["precision"] == "fp32" else cfg["precision"], "data": "synthetic",
             "config": {"workload": cfg["what"], "name": args.config,
                        "gemm_precision": "f32 MFMA (exact)" if cfg["precision"] == "fp32" else
-                       f"split-bf16 MFMA ({cfg['precision']}) in qkv_kv / mlp0 / mlp3 via GATSSPG_FLAG_PREC_{cfg['precision'].upper()}; "
+                       f"split-{cfg['precision'][:4]} MFMA ({cfg['precision']}) in qkv_kv / mlp0 / mlp3 via GATSSPG_FLAG_PREC_{cfg['precision'].upper()}; "
                        "final_proj, score, GATs fp32",
                        "n_2d": n1, "n_3d": n2, "num_leaf": NUM_LEAF, "batch": bsz, "steps_per_gpu": K, "frames_per_gpu": K * bsz,
                        "frames_in_flight_per_gpu": S * bsz, "timed_pass_repetitions": R,
@@ -840,7 +846,8 @@ def main():
                 side, note="same workload, same entry point, one flags bit (GATSSPG_FLAG_PREC_*); measured after the timed passes, "
                            "never part of value.  bf16x6: every fp32 operand split EXACTLY into three bf16 planes, six bf16 MFMA "
                            "products per fp32 product (dropped terms <= 2^-24 |ab|), fp32 accumulation: fp32-class arithmetic. "
-                           "bf16x3: two planes, three products (~2^-16 relative)")
+                           "bf16x3: two planes, three products (~2^-16 relative).  fp16x3: two fp16 terms (2 x 11 significand bits, ~2^-20 relative), "
+                           "three fp16 MFMA products")
         if world == 1 and not args.no_cpu_baseline and args.config == "headline":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -111,7 +111,14 @@ struct AttnWB {
     static constexpr size_t QKV_LO2 = W3_LO + 256 * 512;
     static constexpr size_t W0_LO2 = QKV_LO2 + 768 * 256;
     static constexpr size_t W3_LO2 = W0_LO2 + 512 * 512;
-    static constexpr size_t SIZE = W3_LO2 + 256 * 512;
+    // fp16 hi / lo planes (GATSSPG_FLAG_PREC_FP16X3): hi = RTZ_fp16(w), lo = RTZ_fp16(w - hi), same slab-major layout
+    static constexpr size_t QKV_H16 = W3_LO2 + 256 * 512;
+    static constexpr size_t QKV_L16 = QKV_H16 + 768 * 256;
+    static constexpr size_t W0_H16 = QKV_L16 + 768 * 256;
+    static constexpr size_t W0_L16 = W0_H16 + 512 * 512;
+    static constexpr size_t W3_H16 = W0_L16 + 512 * 512;
+    static constexpr size_t W3_L16 = W3_H16 + 256 * 512;
+    static constexpr size_t SIZE = W3_L16 + 256 * 512;
 };
 constexpr size_t PWB_TOTAL = 8 * AttnWB::SIZE;                   // bf16 elements
 constexpr size_t PACKED_BYTES = sizeof(float) * PW_TOTAL + sizeof(unsigned short) * PWB_TOTAL;
@@ -119,7 +126,7 @@ constexpr size_t PACKED_BYTES = sizeof(float) * PW_TOTAL + sizeof(unsigned short
 // ---- workspace carve-up ---------------------------------------------------------------------------
 struct Workspace {
     ColLayout L;
-    int prec;          // 0: fp32 MFMA; 1: three-term split-bf16 (bf16x3), 2: six-term (bf16x6) main loops in qkv_kv / mlp0 / mlp3 (from the call's flags)
+    int prec;          // 0: fp32 MFMA; 1: three-term split-bf16 (bf16x3), 2: six-term (bf16x6), 3: three-term split-fp16 (fp16x3) main loops in qkv_kv / mlp0 / mlp3 (from the call's flags)
     int nt64;          // ld / 64 column tiles
     int nseg;          // 2*b
     int sc_nct, sc_nrt;   // score kernel tiles per frame (n2p/SC_BN, n1p/SC_BM)

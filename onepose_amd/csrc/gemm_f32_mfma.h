@@ -420,6 +420,20 @@ __device__ __forceinline__ void bf16_split2(float a, float b, unsigned& hi, unsi
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){ra, rb}, bf16x2));
 }
 
+// The same two-term idea on IEEE fp16 terms ("fp16x3", GATSSPG_FLAG_PREC_FP16X3): x ~ x1 + x2 with x1 = RTZ_fp16(x) -- round
+// toward zero never overflows to infinity, it saturates at 65504 -- and x2 = RTZ_fp16(x - x1): 2 x 11 significand bits, i.e. a
+// representation error <= 2^-20 |x| (bf16x3: 2^-16) as long as x2 stays a normal fp16 number (|x| >~ 0.06; below that the
+// absolute error is the fp16 subnormal spacing, 6e-8).  Three v_mfma_f32_32x32x16_f16 per 32x32x16 block, fp32 accumulation:
+// the matrix-pipe time of bf16x3 at (measured) fp32-class results.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fp16_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    hi = __builtin_bit_cast(unsigned, h);
+    const float ra = a - (float)h[0], rb = b - (float)h[1];
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+
 template <class T>
 struct Bf3Layout {
     static constexpr int KS = 40;                                       // bf16 per LDS row (32 + 8 pad)
@@ -436,7 +450,10 @@ struct Bf3Layout {
 // a_hi(kt) / a_lo(kt): bf16 plane pointers of A slab kt (&A[row0][kt*32], row stride lda elements).
 // b_slab(kt): fp32 pointer &B[kt*32][col0], row stride ldb.  x_mean / x_rstd / bxform: per-k-row aux values applied to
 // the B values before the split (mlp.3: InstanceNorm + ReLU on the operand load).
-template <class T, class AHi, class ALo, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, class Hooks = NoHooks>
+// F16: the two planes of each operand hold fp16 terms (fp16_split2) and the products run on v_mfma_f32_32x32x16_f16; layouts,
+// staging and pipeline are those of the bf16 form (16-bit elements either way).
+template <class T, class AHi, class ALo, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, class Hooks = NoHooks,
+          bool F16 = false>
 __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, AHi a_hi, ALo a_lo,
                                                      int lda, BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform,
                                                      Hooks* hooks = nullptr) {
@@ -503,7 +520,8 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
                 v0 = bxform(v0, rx[j]);
                 v1 = bxform(v1, rx[j + 1]);
             }
-            bf16_split2(v0, v1, h[j / 2], l[j / 2]);
+            if constexpr (F16) fp16_split2(v0, v1, h[j / 2], l[j / 2]);
+            else bf16_split2(v0, v1, h[j / 2], l[j / 2]);
         }
         if constexpr (KPT == 8) {
             *reinterpret_cast<u32x4*>(Bhi + b_soff) = (u32x4){h[0], h[1], h[2], h[3]};
@@ -543,9 +561,16 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][tm], bh[s][tn], acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][tm], bl[s][tn], acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][tm], bh[s][tn], acc[tm][tn], 0, 0, 0);
+                    if constexpr (F16) {
+                        auto h8 = [](bf16x8 v) { return __builtin_bit_cast(f16x8, v); };   // the registers hold fp16 terms in this mode
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al[s][tm]), h8(bh[s][tn]), acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[s][tm]), h8(bl[s][tn]), acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[s][tm]), h8(bh[s][tn]), acc[tm][tn], 0, 0, 0);
+                    } else {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][tm], bh[s][tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][tm], bl[s][tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][tm], bh[s][tn], acc[tm][tn], 0, 0, 0);
+                    }
                 }
     };
     unsigned short* buf0 = smem;
@@ -780,12 +805,12 @@ __device__ __forceinline__ void gemm_mainloop_bf6_ex(f32x16 (&acc)[T::TM][T::TN]
 struct NoXform1 {
     __device__ __forceinline__ float operator()(float v, float2) const { return v; }
 };
-template <class T, class AHi, class ALo, class BSlab, class Hooks = NoHooks>
+template <class T, class AHi, class ALo, class BSlab, class Hooks = NoHooks, bool F16 = false>
 __device__ __forceinline__ void gemm_mainloop_bf3(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, AHi a_hi, ALo a_lo,
                                                   int lda, BSlab b_slab, int ldb, Hooks* hooks = nullptr) {
     auto nox = [](int) { return static_cast<const float*>(nullptr); };
-    gemm_mainloop_bf3_ex<T, AHi, ALo, BSlab, decltype(nox), decltype(nox), NoXform1, false, Hooks>(acc, smem, KT, a_hi, a_lo, lda, b_slab,
-                                                                                                 ldb, nox, nox, NoXform1(), hooks);
+    gemm_mainloop_bf3_ex<T, AHi, ALo, BSlab, decltype(nox), decltype(nox), NoXform1, false, Hooks, F16>(acc, smem, KT, a_hi, a_lo, lda,
+                                                                                                      b_slab, ldb, nox, nox, NoXform1(), hooks);
 }
 
 template <class T, class APlane, class BSlab, class Hooks = NoHooks>

@@ -25,7 +25,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-PRECISIONS = ["fp32", "bf16x3", "bf16x6"]   # every golden / headline test runs under all GEMM arithmetics (include/gatsspg.h)
+PRECISIONS = ["fp32", "bf16x3", "bf16x6", "fp16x3"]   # every golden / headline test runs under all GEMM arithmetics (include/gatsspg.h)
 
 
 def make_model(sd, hp, precision="fp32"):
@@ -294,7 +294,8 @@ def test_benchmarked_shapes_vs_reference_golden(name, precision, bench_golden_me
     the 1000/20000 stress shape (configs[4]) and OnePose's own 500/2000 operating point (b=1, b=8: `bench.py --config real`): conf sub-sample / row+col maxima within 1e-4 of the REFERENCE's own
     output, raw arg-max indices and matches identical.  An index may differ only where the reference's top-2 gap is below
     what the arithmetic resolves (conftest.TIE_GAP); the count is printed.  fp32 and bf16x6: zero flips on every case.
-    bf16x3: at most a handful per 64000 arg-maxes, each at a reference gap < 1e-3 (measured: one or two, in head_b8)."""
+    bf16x3: at most a handful per 64000 arg-maxes, each at a reference gap < 1e-3 (measured: one or two, in head_b8).
+    fp16x3: only at reference gaps < 2e-5 (the fp32 tie gap; measured: one, in head_b8, at the 1.9e-6 gap)."""
     mc = bench_golden_meta["cases"][name]
     g = load_golden("bench_" + name)
     sd, data, hp = case_inputs(mc)
@@ -305,7 +306,7 @@ def test_benchmarked_shapes_vs_reference_golden(name, precision, bench_golden_me
                              f"{name}[{precision}]", tie_gap=TIE_GAP[precision])
     print(f"{name} [{precision}]: {res}")
     flips = res["flips_rows"] + res["flips_cols"]
-    assert flips == 0 if precision != "bf16x3" else flips <= 8
+    assert flips <= {"bf16x3": 8, "fp16x3": 2}.get(precision, 0)
     if precision != "fp32":   # the two arithmetics agree far inside the tolerance
         pred32, conf32 = make_model(sd, hp, "fp32")(d)
         dc = float((conf - conf32).abs().max())
@@ -532,7 +533,7 @@ def _random_cases(n=24, seed=2024):
         if i >= 14:   # round 2: larger shapes that straddle the finalize chunks (512 columns) and strips (16 rows), both arithmetics
             n1 = int(rs.choice([130, 513, 777, 1025]))
             n2 = int(rs.choice([511, 513, 1030, 1537, 2049]))
-        cases.append((i, b, n1, n2, L, flags, ("fp32", "bf16x6", "bf16x3")[i % 3]))
+        cases.append((i, b, n1, n2, L, flags, ("fp32", "bf16x6", "bf16x3", "fp16x3")[i % 4]))
     return cases
 
 

@@ -38,7 +38,7 @@ def test_host_only_entry_points(lib):
     assert lib.gatsspg_version() >= 300
     big = 768 * 256 + 512 * 512 + 256 * 512           # the three big operators of an attention layer
     assert lib.gatsspg_packed_weights_bytes() == (4 * (8 * (big + 768 + 512 + 256) + 4 * (512 + 256 * 256) + 256 * 256 + 256)
-                                                  + 2 * 3 * 8 * big)   # + their three bf16 planes (hi / lo / lo2)
+                                                  + 2 * 5 * 8 * big)   # + their three bf16 planes (hi / lo / lo2) and two fp16 planes
     small = lib.gatsspg_workspace_bytes(1, 500, 2000, 8)
     head = lib.gatsspg_workspace_bytes(1, 1000, 7000, 8)
     assert 0 < small < head < 200 * 2**20
