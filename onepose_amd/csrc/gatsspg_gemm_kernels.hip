@@ -38,7 +38,7 @@ using QkvTileB = GemmTile<128, QKV_BN, 2, 2, false>;      // split-bf16 alternat
 // (forcing 80 VGPRs so that three 8-wave workgroups fit a CU -- the 756 tiles of the headline shape then fit 768 slots in one
 // round -- was measured: kernel -2 %, frames/s in flight unchanged; not kept)
 template <class T, int PREC = 0>
-__global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void qkv_kv_kernel(const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
+__global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel(const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
                                                             const unsigned short* __restrict__ Whi,
                                                             const unsigned short* __restrict__ Wlo,
                                                             const unsigned short* __restrict__ Wl2,
@@ -326,7 +326,7 @@ static constexpr unsigned long long* g_trace = nullptr;
 
 // ABL (profiling builds only, wrong results): main-loop ablations of gemm_mainloop_ex.  PREC as in qkv_kv_kernel.
 template <class T, int ABL = 0, int PREC = 0>
-__global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
+__global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                    const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
                                                    const unsigned short* __restrict__ Wl2,
                                                    const float* __restrict__ Z, const float* __restrict__ Qbuf,
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp0_kernel(c
     const float* A = W0 + (size_t)rt * T::BM * 512;
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % T::WAVES_MN;   // (K-split tiles: wave within its group)
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
-    // requested before the main loop (see qkv_kv_kernel); the six-term loop has no 16 registers to park it in (128-VGPR budget of
-    // two 8-wave workgroups per CU) and fetches it after the loop
+    // requested before the main loop (see qkv_kv_kernel); the six-term and the fp16 loops have no 16 registers to park it in
+    // (128-VGPR budget of two 8-wave workgroups per CU) and fetch it after the loop
     float bias[T::TM][16];
     auto load_bias = [&]() {
 #pragma unroll
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp0_kernel(c
                 bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
             }
     };
-    if constexpr (PREC != 2) load_bias();
+    if constexpr (PREC < 2) load_bias();
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     // ABL == 5 (profiling): every workgroup streams the SAME weight panel and the SAME column tile (cache-hot operands)
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp0_kernel(c
     }
     acc[0][0] = hooks.kept;
     ksplit_reduce<T>(acc, smem);
-    if constexpr (PREC == 2) load_bias();
+    if constexpr (PREC >= 2) load_bias();
     const unsigned long long t_loop = trace ? wall_clock64() : 0;
     constexpr int TS = T::BN + 1;
     float* Tl = smem;  // [BM][BN + 1]
@@ -525,7 +525,7 @@ using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;          // alternative (tuning 
 using Mlp3TileS = GemmTile<64, 64, 2, 2, false, false, 2>;   // fp32, launches that leave CUs empty: 64x64, two K groups of 4 waves
 
 template <class T, int ABL = 0, int PREC = 0>
-__global__ __launch_bounds__(T::THREADS, (PREC == 2 ? 4 : 1)) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
+__global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
                                                    const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
                                                    const unsigned short* __restrict__ Wl2,
                                                    const float* __restrict__ U, const float* __restrict__ stats,
