@@ -83,12 +83,13 @@ def split_matmul(a, b, mode):
     """a [m,k] @ b [k,n] with the operand splitting of `mode`, fp32 accumulation."""
     if mode == "fp32":
         return a @ b
-    terms = {"bf16": 1, "bf16x3": 2, "bf16x6": 3, "fp16": 1, "fp16x3": 2, "fp16x3rtz": 2, "fp16x3zn": 2}[mode]
-    split = (fp16_split_rtz if mode == "fp16x3rtz" else fp16_split_rtz_rne if mode == "fp16x3zn" else fp16_split if mode.startswith("fp16")
+    terms = {"bf16": 1, "bf16x3": 2, "bf16x6": 3, "fp16": 1, "fp16x3": 2, "fp16x3rtz": 2, "fp16x3zn": 2, "fp16x4": 2, "fp16x4zn": 2,
+             "fp16x4rtz": 2}[mode]
+    split = (fp16_split_rtz if mode.endswith("rtz") else fp16_split_rtz_rne if mode.endswith("zn") else fp16_split if mode.startswith("fp16")
              else bf16_trunc_split)
     ap, bp = split(a, terms), split(b, terms)
     out = np.zeros((a.shape[0], b.shape[1]), F32)
-    max_order = {"bf16": 0, "bf16x3": 1, "bf16x6": 2, "fp16": 0, "fp16x3": 1, "fp16x3rtz": 1, "fp16x3zn": 1}[mode]
+    max_order = {"bf16": 0, "bf16x3": 1, "bf16x6": 2, "fp16": 0, "fp16x3": 1, "fp16x3rtz": 1, "fp16x3zn": 1, "fp16x4": 2, "fp16x4zn": 2, "fp16x4rtz": 2}[mode]
     pairs = sorted(((i, j) for i in range(terms) for j in range(terms) if i + j <= max_order), key=lambda t: -(t[0] + t[1]))
     for i, j in pairs:                      # small terms first
         out += ap[i] @ bp[j]
