@@ -518,6 +518,12 @@ CONFIGS = {
     "fp16x3-b8": dict(b=8, n1=1000, n2=7000, precision="fp16x3", golden="head_b8",
                       what="BASELINE configs[2] shape, 8 frames of 1000/7000 per step, attention-layer GEMMs on three-term split-fp16 MFMA "
                            "(the dtype BASELINE configs[3] names, made to meet the parity bar); reported separately, never the headline value"),
+    "fp16x4": dict(b=1, n1=1000, n2=7000, precision="fp16x4", golden="head_rand",
+                   what="headline shape (1000/7000, batch 1) with the attention-layer GEMMs on four-term split-fp16 MFMA (two fp16 terms per "
+                        "operand, all 4 products: fp32-class arithmetic in four MFMAs); reported separately, never the headline value"),
+    "fp16x4-b8": dict(b=8, n1=1000, n2=7000, precision="fp16x4", golden="head_b8",
+                      what="BASELINE configs[2] shape, 8 frames of 1000/7000 per step, attention-layer GEMMs on four-term split-fp16 MFMA "
+                           "(fp32-class: match indices bit-exact against the reference golden); reported separately, never the headline value"),
     "bf16x6-b8": dict(b=8, n1=1000, n2=7000, precision="bf16x6", golden="head_b8",
                       what="BASELINE configs[2] ('bf16 MFMA, 64 frames sharded 8 per GPU') -- THE configs[2] line: 8 frames of "
                            "1000/7000 per step, attention-layer GEMMs on six-term split-bf16 MFMA (fp32-class: match indices "
@@ -759,7 +765,7 @@ def main():
     side = None
     # (a multi-rank job skips them: ranks 1..N-1 would sit in the metrics all_gather while rank 0 runs two untimed passes)
     if rank == 0 and world == 1 and args.config == "headline" and not args.shape and not args.no_side_arithmetics:
-        side = {p: side_arithmetic(device, cfg, p, base.shared_inputs, K, W, S) for p in ("bf16x6", "fp16x3", "bf16x3")}
+        side = {p: side_arithmetic(device, cfg, p, base.shared_inputs, K, W, S) for p in ("bf16x6", "fp16x4", "fp16x3", "bf16x3")}
 
     amortised = None
     if args.amortised:
@@ -788,7 +794,7 @@ def main():
 
     if rank == 0:
         n1, n2, bsz = cfg["n1"], cfg["n2"], runner.b
-        nterms = {"fp32": 0, "bf16x3": 3, "bf16x6": 6, "fp16x3": 3}[cfg["precision"]]
+        nterms = {"fp32": 0, "bf16x3": 3, "bf16x6": 6, "fp16x3": 3, "fp16x4": 4}[cfg["precision"]]
         split = nterms and args.kernel in ("mlp0", "qkv_kv", "mlp3")
         fl = kernel_flops(args.kernel, n1, n2) * bsz
         achieved = fl / (kern_ms * 1e-3) / 1e12
@@ -847,7 +853,7 @@ def main():
                            "never part of value.  bf16x6: every fp32 operand split EXACTLY into three bf16 planes, six bf16 MFMA "
                            "products per fp32 product (dropped terms <= 2^-24 |ab|), fp32 accumulation: fp32-class arithmetic. "
                            "bf16x3: two planes, three products (~2^-16 relative).  fp16x3: two fp16 terms (2 x 11 significand bits, ~2^-20 relative), "
-                           "three fp16 MFMA products")
+                           "three fp16 MFMA products; fp16x4: all four products of the same terms (fp32-class)")
         if world == 1 and not args.no_cpu_baseline and args.config == "headline":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -54,13 +54,16 @@ extern "C" {
  * final_proj, the score contraction, GATs and all reductions are fp32 in every mode. */
 #define GATSSPG_FLAG_PREC_BF16X3 0x100
 #define GATSSPG_FLAG_PREC_BF16X6 0x200
-/*   GATSSPG_FLAG_PREC_FP16X3: three-term split on IEEE fp16 -- every fp32 operand is x1 + x2 with x1 = RTZ_fp16(x) (round toward
- *     zero: saturates at 65504, never produces infinity) and x2 = RTZ_fp16(x - x1), i.e. 2 x 11 significand bits (bf16x3: 2 x 8),
- *     and each product three v_mfma_f32_32x32x16_f16 with fp32 accumulation: the matrix-pipe time of bf16x3 at 16x its operand
- *     precision (BASELINE configs[3] names fp16; a SINGLE fp16 term fails the parity bar like a single bf16 term does).  Operands
- *     beyond +-131008 lose precision (they saturate), operands below ~0.06 in magnitude keep an absolute error of 6e-8 (fp16
- *     subnormal spacing).  Measured parity in DESIGN.md 12d / tests/test_hip_parity.py.  The three precision bits are exclusive. */
+/*   GATSSPG_FLAG_PREC_FP16X3 / _FP16X4: two-term split on IEEE fp16 -- every fp32 operand is x1 + x2 with x1 = RNE_fp16(x),
+ *     x2 = RNE_fp16(x - x1), i.e. 2 x 11 significand bits with a signed remainder (|x - x1 - x2| <= 2^-23 |x|; bf16x3: 2^-16), both
+ *     conversions clamped to +-65504 so that an out-of-range operand saturates instead of becoming infinity (operands beyond
+ *     +-131008 lose precision; operands below ~0.06 in magnitude keep an absolute error of 6e-8, the fp16 subnormal spacing).
+ *     FP16X3: the three leading products on v_mfma_f32_32x32x16_f16 -- the matrix-pipe time of bf16x3 (BASELINE configs[3] names
+ *     fp16; a SINGLE fp16 term fails the parity bar like a single bf16 term does).  FP16X4: all four products, the exact product
+ *     of the split operands with fp32 accumulation -- fp32-class results in four MFMAs where bf16x6 needs six.  Measured parity in
+ *     DESIGN.md 12d / tests/test_hip_parity.py.  The four precision bits are exclusive. */
 #define GATSSPG_FLAG_PREC_FP16X3 0x400
+#define GATSSPG_FLAG_PREC_FP16X4 0x800
 /* layer kinds for gatsspg_attn_layer (GATs_SuperGlue.py:55-64) */
 #define GATSSPG_LAYER_SELF 0
 #define GATSSPG_LAYER_CROSS 1

@@ -16,7 +16,8 @@ FLAG_INCLUDE_SELF, FLAG_ADDITIONAL, FLAG_WITH_LINEAR_TRANSFORM = 1, 2, 4
 FLAG_PREC_BF16X3 = 0x100
 FLAG_PREC_BF16X6 = 0x200
 FLAG_PREC_FP16X3 = 0x400
-PRECISIONS = {"fp32": 0, "bf16x3": FLAG_PREC_BF16X3, "bf16x6": FLAG_PREC_BF16X6, "fp16x3": FLAG_PREC_FP16X3}   # GEMM arithmetic of the attention layers, selected per call
+FLAG_PREC_FP16X4 = 0x800
+PRECISIONS = {"fp32": 0, "bf16x3": FLAG_PREC_BF16X3, "bf16x6": FLAG_PREC_BF16X6, "fp16x3": FLAG_PREC_FP16X3, "fp16x4": FLAG_PREC_FP16X4}   # GEMM arithmetic of the attention layers, selected per call
 KERNEL_IDS = {"load_state": 0, "gats": 1, "qkv_kv": 2, "kv_final": 3, "mlp0": 5, "stat_final": 6,
               "mlp3": 7, "final_proj_norm": 8, "score_exp": 9, "conf_finalize": 10, "match_tail": 11, "gats_wlt": 12,
               "softmax_stats": 13}

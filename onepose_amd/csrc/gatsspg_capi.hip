@@ -37,13 +37,13 @@ int check_ws(const void* ws, size_t ws_bytes, int b, int n1, int n2, int num_lea
     if (int e = check_dims(b, n1, n2, num_leaf)) return e;
     if (!ws) return fail("workspace pointer is null");
     if (reinterpret_cast<uintptr_t>(ws) & 15) return fail("workspace must be 16-byte aligned");
-    constexpr int PREC_BITS = GATSSPG_FLAG_PREC_BF16X3 | GATSSPG_FLAG_PREC_BF16X6 | GATSSPG_FLAG_PREC_FP16X3;
+    constexpr int PREC_BITS = GATSSPG_FLAG_PREC_BF16X3 | GATSSPG_FLAG_PREC_BF16X6 | GATSSPG_FLAG_PREC_FP16X3 | GATSSPG_FLAG_PREC_FP16X4;
     if (flags & ~(GATSSPG_FLAG_INCLUDE_SELF | GATSSPG_FLAG_ADDITIONAL | GATSSPG_FLAG_WITH_LINEAR_TRANSFORM | PREC_BITS))
         return fail("unknown bits in flags (0x%x)", flags);
     const int pb = flags & PREC_BITS;
-    if (pb & (pb - 1)) return fail("GATSSPG_FLAG_PREC_BF16X3, _BF16X6 and _FP16X3 are exclusive");
+    if (pb & (pb - 1)) return fail("GATSSPG_FLAG_PREC_BF16X3, _BF16X6, _FP16X3 and _FP16X4 are exclusive");
     w = carve_workspace(const_cast<void*>(ws), b, n1, n2);
-    w.prec = (flags & GATSSPG_FLAG_PREC_BF16X6) ? 2 : (flags & GATSSPG_FLAG_PREC_BF16X3) ? 1 : (flags & GATSSPG_FLAG_PREC_FP16X3) ? 3 : 0;
+    w.prec = (flags & GATSSPG_FLAG_PREC_BF16X6) ? 2 : (flags & GATSSPG_FLAG_PREC_BF16X3) ? 1 : (flags & GATSSPG_FLAG_PREC_FP16X3) ? 3 : (flags & GATSSPG_FLAG_PREC_FP16X4) ? 4 : 0;
     if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu bytes", ws_bytes, w.bytes);
     return 0;
 }

@@ -111,7 +111,7 @@ struct AttnWB {
     static constexpr size_t QKV_LO2 = W3_LO + 256 * 512;
     static constexpr size_t W0_LO2 = QKV_LO2 + 768 * 256;
     static constexpr size_t W3_LO2 = W0_LO2 + 512 * 512;
-    // fp16 hi / lo planes (GATSSPG_FLAG_PREC_FP16X3): hi = RTZ_fp16(w), lo = RTZ_fp16(w - hi), same slab-major layout
+    // fp16 hi / lo planes (GATSSPG_FLAG_PREC_FP16X3 / _FP16X4): hi = RNE_fp16(w), lo = RNE_fp16(w - hi) (clamped), same slab-major layout
     static constexpr size_t QKV_H16 = W3_LO2 + 256 * 512;
     static constexpr size_t QKV_L16 = QKV_H16 + 768 * 256;
     static constexpr size_t W0_H16 = QKV_L16 + 768 * 256;
@@ -126,7 +126,7 @@ constexpr size_t PACKED_BYTES = sizeof(float) * PW_TOTAL + sizeof(unsigned short
 // ---- workspace carve-up ---------------------------------------------------------------------------
 struct Workspace {
     ColLayout L;
-    int prec;          // 0: fp32 MFMA; 1: three-term split-bf16 (bf16x3), 2: six-term (bf16x6), 3: three-term split-fp16 (fp16x3) main loops in qkv_kv / mlp0 / mlp3 (from the call's flags)
+    int prec;          // 0: fp32 MFMA; 1: three-term split-bf16 (bf16x3), 2: six-term (bf16x6), 3 / 4: three- / four-term split-fp16 (fp16x3, fp16x4) main loops in qkv_kv / mlp0 / mlp3 (from the call's flags)
     int nt64;          // ld / 64 column tiles
     int nseg;          // 2*b
     int sc_nct, sc_nrt;   // score kernel tiles per frame (n2p/SC_BN, n1p/SC_BM)

@@ -11,7 +11,7 @@ namespace gatsspg {
 template <class T, int PREC = 0>
 constexpr size_t smem_bytes() {
     size_t b = sizeof(float) * T::SMEM_FLOATS;
-    if constexpr (PREC == 1 || PREC == 3) {
+    if constexpr (PREC == 1 || PREC >= 3) {
         if (Bf3Layout<T>::SMEM_BYTES > b) b = Bf3Layout<T>::SMEM_BYTES;
     }
     if constexpr (PREC == 2) {
@@ -69,14 +69,14 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel
     if constexpr (PREC != 2) load_bias();
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
-    if constexpr (PREC == 1 || PREC == 3) {   // PREC == 3: the planes hold fp16 terms, the products run on the f16 MFMA
+    if constexpr (PREC == 1 || PREC >= 3) {   // PREC >= 3: the planes hold fp16 terms, the products run on the f16 MFMA (4: four products)
         // weight planes are slab-major ([K/32][rows][32], split_weights_kernel): a 128 x 32 slab is 8 KB of consecutive bytes
         const size_t ro = (size_t)rt * 128 * BK;
         auto ah = [&](int kt) { return Whi + ro + (size_t)kt * 768 * BK; };
         auto alo = [&](int kt) { return Wlo + ro + (size_t)kt * 768 * BK; };
         auto bl = [&](int kt) { return Z + (size_t)kt * BK * ld + c0; };
-        gemm_mainloop_bf3<T, decltype(ah), decltype(alo), decltype(bl), NoHooks, PREC == 3>(acc, reinterpret_cast<unsigned short*>(smem),
-                                                                                             D / BK, ah, alo, BK, bl, ld);
+        gemm_mainloop_bf3<T, decltype(ah), decltype(alo), decltype(bl), NoHooks, (PREC >= 3), (PREC == 4 ? 4 : 3)>(
+            acc, reinterpret_cast<unsigned short*>(smem), D / BK, ah, alo, BK, bl, ld);
     } else if constexpr (PREC == 2) {
         const size_t ro = (size_t)rt * 128 * BK;
         gemm_mainloop_bf6<T>(
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
     } else {
         // split planes in the slab-major layout of the weight planes: (m, k) at ((k / 32) * 512 + m) * 32 + k % 32
         unsigned p0a, p1a, p2a = 0, p0b, p1b, p2b = 0;
-        if (prec == 3) {   // fp16 terms
+        if (prec >= 3) {   // fp16 terms
             fp16_split2(o0, o1, p0a, p1a);
             fp16_split2(o2, o3, p0b, p1b);
         } else {
@@ -372,12 +372,12 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(c
     auto bl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : Qbuf + (size_t)(kt - 8) * BK * ld) + ch0; };
     AttnFoldHooks hooks;
     hooks.init(ksumT + (size_t)ts.seg * H * DH, smem + smem_floats_mainloop<T, PREC>(), wn);
-    if constexpr (PREC == 1 || PREC == 3) {
+    if constexpr (PREC == 1 || PREC >= 3) {
         const size_t ro = (size_t)rt * T::BM * BK;   // slab-major planes (see qkv_kv_kernel); M_t planes in the same layout
         const unsigned short* Mh = Mpl + (size_t)ts.seg * 3 * MPL_PLANE + ro;
         auto ah = [&](int kt) { return kt < 8 ? Whi + ro + (size_t)kt * 512 * BK : Mh + (size_t)(kt - 8) * 512 * BK; };
         auto alo = [&](int kt) { return kt < 8 ? Wlo + ro + (size_t)kt * 512 * BK : Mh + MPL_PLANE + (size_t)(kt - 8) * 512 * BK; };
-        gemm_mainloop_bf3<T, decltype(ah), decltype(alo), decltype(bl), AttnFoldHooks, PREC == 3>(
+        gemm_mainloop_bf3<T, decltype(ah), decltype(alo), decltype(bl), AttnFoldHooks, (PREC >= 3), (PREC == 4 ? 4 : 3)>(
             acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, ah, alo, BK, bl, ld, &hooks);
     } else if constexpr (PREC == 2) {
         const size_t ro = (size_t)rt * T::BM * BK;
@@ -563,13 +563,14 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp3_kernel(c
     auto bl = [&](int kt) { return U + (size_t)kt * BK * ld + c0; };
     auto xm = [&](int kt) { return mean + kt * BK; };
     auto xr = [&](int kt) { return rstd + kt * BK; };
-    if constexpr (PREC == 1 || PREC == 3) {
+    if constexpr (PREC == 1 || PREC >= 3) {
         const size_t ro = (size_t)rt * T::BM * BK;   // slab-major planes (see qkv_kv_kernel)
         auto ah = [&](int kt) { return Whi + ro + (size_t)kt * 256 * BK; };
         auto alo = [&](int kt) { return Wlo + ro + (size_t)kt * 256 * BK; };
         auto bx1 = [](float v, float2 ms) { return fmaxf((v - ms.x) * ms.y, 0.f); };
         gemm_mainloop_bf3_ex<T, decltype(ah), decltype(alo), decltype(bl), decltype(xm), decltype(xr), decltype(bx1), true, NoHooks,
-                             PREC == 3>(acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, ah, alo, BK, bl, ld, xm, xr, bx1);
+                             (PREC >= 3), (PREC == 4 ? 4 : 3)>(acc, reinterpret_cast<unsigned short*>(smem), 512 / BK, ah, alo, BK, bl, ld, xm,
+                                                               xr, bx1);
     } else if constexpr (PREC == 2) {
         const size_t ro = (size_t)rt * T::BM * BK;
         auto ap = [&](int kt, int pl) { return (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + (size_t)kt * 256 * BK; };
@@ -844,8 +845,8 @@ static void launch_qkv_t(const float* Wqkv, const float* bqkv, const unsigned sh
     const int NT = active_tiles(w.L);
     allow_big_lds<qkv_kv_kernel<T, PREC>>();
     GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_kernel<T, PREC>), dim3(xcd_grid(6, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>()), s,
-                   Wqkv, bqkv, wb ? wb + (PREC == 3 ? AttnWB::QKV_H16 : AttnWB::QKV_HI) : nullptr,
-                   wb ? wb + (PREC == 3 ? AttnWB::QKV_L16 : AttnWB::QKV_LO) : nullptr, wb ? wb + AttnWB::QKV_LO2 : nullptr, w.Z,
+                   Wqkv, bqkv, wb ? wb + (PREC >= 3 ? AttnWB::QKV_H16 : AttnWB::QKV_HI) : nullptr,
+                   wb ? wb + (PREC >= 3 ? AttnWB::QKV_L16 : AttnWB::QKV_LO) : nullptr, wb ? wb + AttnWB::QKV_LO2 : nullptr, w.Z,
                    w.Q, w.kvpart, w.L);
 }
 
@@ -856,6 +857,7 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* w
     else if (w.prec == 1) launch_qkv_t<QkvTileW8, 1>(Wqkv, bqkv, wb, w, s, hk);
     else if (w.prec == 2) launch_qkv_t<QkvTileW8, 2>(Wqkv, bqkv, wb, w, s, hk);
     else if (w.prec == 3) launch_qkv_t<QkvTileW8, 3>(Wqkv, bqkv, wb, w, s, hk);
+    else if (w.prec == 4) launch_qkv_t<QkvTileW8, 4>(Wqkv, bqkv, wb, w, s, hk);
     else launch_qkv_t<QkvTileW8, 0>(Wqkv, bqkv, wb, w, s, hk);
 }
 
@@ -872,7 +874,7 @@ static void launch_mlp0_t(const float* W0, const float* b0, const unsigned short
     const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
     GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_kernel<T, ABL, PREC>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
                    (smem_bytes<T, PREC>() + sizeof(float) * AttnFoldHooks::ZP_FLOATS), s, W0, b0,
-                   wb ? wb + (PREC == 3 ? AttnWB::W0_H16 : AttnWB::W0_HI) : nullptr, wb ? wb + (PREC == 3 ? AttnWB::W0_L16 : AttnWB::W0_LO) : nullptr,
+                   wb ? wb + (PREC >= 3 ? AttnWB::W0_H16 : AttnWB::W0_HI) : nullptr, wb ? wb + (PREC >= 3 ? AttnWB::W0_L16 : AttnWB::W0_LO) : nullptr,
                    wb ? wb + AttnWB::W0_LO2 : nullptr, w.Z, w.Q, w.Mop, w.Mpl, w.ksumT, w.U,
                    w.statpart, w.L, g_trace);
 }
@@ -882,8 +884,8 @@ static void launch_mlp3_t(const float* W3, const float* b3, const unsigned short
     allow_big_lds<mlp3_kernel<T, ABL, PREC>>();
     const int NT = active_tiles(w.L) / (T::BN / 64);
     GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_kernel<T, ABL, PREC>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS),
-                   (smem_bytes<T, PREC>()), s, W3, b3, wb ? wb + (PREC == 3 ? AttnWB::W3_H16 : AttnWB::W3_HI) : nullptr,
-                   wb ? wb + (PREC == 3 ? AttnWB::W3_L16 : AttnWB::W3_LO) : nullptr, wb ? wb + AttnWB::W3_LO2 : nullptr, w.U,
+                   (smem_bytes<T, PREC>()), s, W3, b3, wb ? wb + (PREC >= 3 ? AttnWB::W3_H16 : AttnWB::W3_HI) : nullptr,
+                   wb ? wb + (PREC >= 3 ? AttnWB::W3_L16 : AttnWB::W3_LO) : nullptr, wb ? wb + AttnWB::W3_LO2 : nullptr, w.U,
                    w.stats, w.Z, w.L);
 }
 
@@ -902,6 +904,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else if (w.prec == 1) launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, wb, w, s, hk);
     else if (w.prec == 2) launch_mlp0_t<Mlp0TileW8, 0, 2>(W0, b0, wb, w, s, hk);
     else if (w.prec == 3) launch_mlp0_t<Mlp0TileW8, 0, 3>(W0, b0, wb, w, s, hk);
+    else if (w.prec == 4) launch_mlp0_t<Mlp0TileW8, 0, 4>(W0, b0, wb, w, s, hk);
 #ifdef GATSSPG_PROFILING_BUILD
     else if (t0 == 11) launch_mlp0_t<Mlp0TileW8, 1, 0>(W0, b0, wb, w, s, hk);   // no global loads in the loop
     else if (t0 == 12) launch_mlp0_t<Mlp0TileW8, 2, 0>(W0, b0, wb, w, s, hk);   // no loads, no LDS writes
@@ -915,6 +918,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else if (w.prec == 1) launch_mlp3_t<Mlp3TileTallW8, 0, 1>(W3, b3, wb, w, s, hk);
     else if (w.prec == 2) launch_mlp3_t<Mlp3TileTallW8, 0, 2>(W3, b3, wb, w, s, hk);
     else if (w.prec == 3) launch_mlp3_t<Mlp3TileTallW8, 0, 3>(W3, b3, wb, w, s, hk);
+    else if (w.prec == 4) launch_mlp3_t<Mlp3TileTallW8, 0, 4>(W3, b3, wb, w, s, hk);
 #ifdef GATSSPG_PROFILING_BUILD
     else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3, 0>(W3, b3, wb, w, s, hk);   // steady-state loop cut: fixed cost only
 #endif

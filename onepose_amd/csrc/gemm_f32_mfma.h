@@ -420,18 +420,23 @@ __device__ __forceinline__ void bf16_split2(float a, float b, unsigned& hi, unsi
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){ra, rb}, bf16x2));
 }
 
-// The same two-term idea on IEEE fp16 terms ("fp16x3", GATSSPG_FLAG_PREC_FP16X3): x ~ x1 + x2 with x1 = RTZ_fp16(x) -- round
-// toward zero never overflows to infinity, it saturates at 65504 -- and x2 = RTZ_fp16(x - x1): 2 x 11 significand bits, i.e. a
-// representation error <= 2^-20 |x| (bf16x3: 2^-16) as long as x2 stays a normal fp16 number (|x| >~ 0.06; below that the
-// absolute error is the fp16 subnormal spacing, 6e-8).  Three v_mfma_f32_32x32x16_f16 per 32x32x16 block, fp32 accumulation:
-// the matrix-pipe time of bf16x3 at (measured) fp32-class results.
+// The same two-term idea on IEEE fp16 terms (GATSSPG_FLAG_PREC_FP16X3 / _FP16X4): x ~ x1 + x2 with x1 = RNE_fp16(x), x2 = RNE_fp16(x - x1):
+// 2 x 11 significand bits with signed remainders, i.e. a representation error <= 2^-23 |x| -- what rounding to fp32 itself costs is
+// 2^-24 -- as long as x2 stays a normal fp16 number (|x| >~ 0.06; below that the absolute error is the fp16 subnormal spacing,
+// 6e-8).  Both conversions are CLAMPED to +-65504 first (v_med3_f32): an out-of-range operand saturates (two terms reach
+// +-131008) instead of becoming infinity and then NaN.  (Round-toward-zero conversions, one instruction per pair and saturating
+// by themselves, were measured first: the one-sided first term doubles the remainder and the mode kept a near-tie flip that the
+// RNE form does not have in the four-product mode -- tests/studies/split_bf16_study.py.)
+//   fp16x3: a1 b1 + a1 b2 + a2 b1              three v_mfma_f32_32x32x16_f16 per 32x32x16 block: the matrix-pipe time of bf16x3
+//   fp16x4: + a2 b2 (first, smallest)          four: the exact product of the split operands -- fp32-class
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void fp16_split2(float a, float b, unsigned& hi, unsigned& lo) {
-    const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const f32x2 ac = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+    const f16x2 h = __builtin_convertvector(ac, f16x2);
     hi = __builtin_bit_cast(unsigned, h);
-    const float ra = a - (float)h[0], rb = b - (float)h[1];
-    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+    const f32x2 r = {__builtin_amdgcn_fmed3f(a - (float)h[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b - (float)h[1], -65504.f, 65504.f)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
 template <class T>
@@ -452,8 +457,9 @@ struct Bf3Layout {
 // the B values before the split (mlp.3: InstanceNorm + ReLU on the operand load).
 // F16: the two planes of each operand hold fp16 terms (fp16_split2) and the products run on v_mfma_f32_32x32x16_f16; layouts,
 // staging and pipeline are those of the bf16 form (16-bit elements either way).
+// NP = 4 (F16 only): the lo x lo product is kept as well (fp16x4).
 template <class T, class AHi, class ALo, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, class Hooks = NoHooks,
-          bool F16 = false>
+          bool F16 = false, int NP = 3>
 __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, AHi a_hi, ALo a_lo,
                                                      int lda, BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform,
                                                      Hooks* hooks = nullptr) {
@@ -563,6 +569,8 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
                 for (int tn = 0; tn < TN; ++tn) {
                     if constexpr (F16) {
                         auto h8 = [](bf16x8 v) { return __builtin_bit_cast(f16x8, v); };   // the registers hold fp16 terms in this mode
+                        if constexpr (NP == 4)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al[s][tm]), h8(bl[s][tn]), acc[tm][tn], 0, 0, 0);
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al[s][tm]), h8(bh[s][tn]), acc[tm][tn], 0, 0, 0);
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[s][tm]), h8(bl[s][tn]), acc[tm][tn], 0, 0, 0);
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[s][tm]), h8(bh[s][tn]), acc[tm][tn], 0, 0, 0);
@@ -805,12 +813,12 @@ __device__ __forceinline__ void gemm_mainloop_bf6_ex(f32x16 (&acc)[T::TM][T::TN]
 struct NoXform1 {
     __device__ __forceinline__ float operator()(float v, float2) const { return v; }
 };
-template <class T, class AHi, class ALo, class BSlab, class Hooks = NoHooks, bool F16 = false>
+template <class T, class AHi, class ALo, class BSlab, class Hooks = NoHooks, bool F16 = false, int NP = 3>
 __device__ __forceinline__ void gemm_mainloop_bf3(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, AHi a_hi, ALo a_lo,
                                                   int lda, BSlab b_slab, int ldb, Hooks* hooks = nullptr) {
     auto nox = [](int) { return static_cast<const float*>(nullptr); };
-    gemm_mainloop_bf3_ex<T, AHi, ALo, BSlab, decltype(nox), decltype(nox), NoXform1, false, Hooks, F16>(acc, smem, KT, a_hi, a_lo, lda,
-                                                                                                      b_slab, ldb, nox, nox, NoXform1(), hooks);
+    gemm_mainloop_bf3_ex<T, AHi, ALo, BSlab, decltype(nox), decltype(nox), NoXform1, false, Hooks, F16, NP>(
+        acc, smem, KT, a_hi, a_lo, lda, b_slab, ldb, nox, nox, NoXform1(), hooks);
 }
 
 template <class T, class APlane, class BSlab, class Hooks = NoHooks>

@@ -391,8 +391,9 @@ class GATsSuperGlue(nn.Module):
     arithmetic of the attention layers' GEMMs for every call of this module: ``"fp32"`` (default: exact fp32 MFMA, the
     reference's arithmetic), ``"bf16x3"`` (split-bf16 MFMA, three bf16 products per fp32 product; conf within 1e-6 of
     the fp32 forward and identical matches on every parity case) or ``"bf16x6"`` (operands split exactly into three bf16
-    planes, six products per fp32 product: fp32-class arithmetic on the bf16 matrix pipe) or ``"fp16x3"`` (two fp16 terms per operand,
-    three fp16 MFMA products: bf16x3's speed at 16x its operand precision; finite operands only up to +-131008).  It travels to the library as a bit of the ``flags``
+    planes, six products per fp32 product: fp32-class arithmetic on the bf16 matrix pipe) ``"fp16x3"`` (two fp16 terms per operand,
+    three fp16 MFMA products: bf16x3's speed at 100x its operand precision; operands saturate beyond +-131008) or ``"fp16x4"`` (the same
+    terms, all four products: fp32-class in four MFMAs).  It travels to the library as a bit of the ``flags``
     argument of the C ABI; nothing is read from the environment."""
 
     def __init__(self, hparams, *, precision="fp32"):

@@ -1,7 +1,7 @@
 """The reference's evaluation loop (inference.py:16-182, configs/experiment/test_GATsSPG.yaml) on the HIP path.
 
     python -m onepose_amd.inference_runner [--data-dir data] [--objects 0408-colorbox-box:colorbox-4 ...]
-                                           [--precision fp32|bf16x3|bf16x6|fp16x3] [--max-frames N]
+                                           [--precision fp32|bf16x3|bf16x6|fp16x3|fp16x4] [--max-frames N]
 
 Per sequence: load the object's annotation (anno_3d_average.npz / anno_3d_collect.npz / idxs.npy under
 ``<sfm_model_dir>/outputs_superpoint_superglue/anno``), keep the 3D database resident on the GPU, then for every cropped
@@ -111,7 +111,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--data-dir", default="data")
     ap.add_argument("--objects", nargs="*", default=list(DEFAULT_OBJECTS), help="<object dir>:<sequence> pairs (test_GATsSPG.yaml input.data_dirs)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x6", "fp16x3"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x6", "fp16x3", "fp16x4"])
     ap.add_argument("--num-leaf", type=int, default=8)
     ap.add_argument("--max-frames", type=int, default=None)
     ap.add_argument("--seed", type=int, default=12345,
