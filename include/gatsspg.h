@@ -56,7 +56,7 @@ extern "C" {
 #define GATSSPG_FLAG_PREC_BF16X6 0x200
 /*   GATSSPG_FLAG_PREC_FP16X3 / _FP16X4: two-term split on IEEE fp16 -- every fp32 operand is x1 + x2 with x1 = RNE_fp16(x),
  *     x2 = RNE_fp16(x - x1), i.e. 2 x 11 significand bits with a signed remainder (|x - x1 - x2| <= 2^-23 |x|; bf16x3: 2^-16), both
- *     conversions clamped to +-65504 so that an out-of-range operand saturates instead of becoming infinity (operands beyond
+ *     conversions saturating at +-65504 (MODE.FP16_OVFL) so that an out-of-range operand never becomes infinity (operands beyond
  *     +-131008 lose precision; operands below ~0.06 in magnitude keep an absolute error of 6e-8, the fp16 subnormal spacing).
  *     FP16X3: the three leading products on v_mfma_f32_32x32x16_f16 -- the matrix-pipe time of bf16x3 (BASELINE configs[3] names
  *     fp16; a SINGLE fp16 term fails the parity bar like a single bf16 term does).  FP16X4: all four products, the exact product

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel
                                                             const float* __restrict__ Z, float* __restrict__ Qbuf,
                                                             float* __restrict__ kvpart, ColLayout L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (PREC >= 3) fp16_saturate_mode();
     int rt, ct;
     if (!xcd_tile_map(6, active_tiles(L), rt, ct)) return;
     ct = global_tile(L, ct);
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
                                                         float* __restrict__ ksumT, ColLayout L, int cross, int prec, int abl) {
     __shared__ float4 red[16][64];
     __shared__ float4 kvs[64];   // this block's final KV^T rows: [4 d][16 float4 of q]
+    if (prec >= 3) fp16_saturate_mode();
     const int tid = threadIdx.x;
     const int el = tid & 63, part = tid >> 6;
     const bool ksum_block = blockIdx.x == 16 * KVF_RS;
@@ -335,6 +337,7 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(c
                                                    float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
                                                    unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (PREC >= 3) fp16_saturate_mode();
     const unsigned long long t_entry = trace ? wall_clock64() : 0;
     const unsigned long long c_entry = trace ? clock64() : 0;
     int rt, ct;
@@ -531,6 +534,7 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp3_kernel(c
                                                    const float* __restrict__ U, const float* __restrict__ stats,
                                                    float* __restrict__ Z, ColLayout L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (PREC >= 3) fp16_saturate_mode();
     int rt, ct;
     constexpr int MT = 256 / T::BM;
     constexpr int TPW = T::BN / 64;   // 64-column tiles per column tile of this kernel
@@ -788,6 +792,7 @@ __global__ __launch_bounds__(256) void gats_wlt_kernel(const float* __restrict__
 
 // one-time split of the three big operators of every attention layer into bf16 hi / lo planes (AttnWB layout)
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ packed, unsigned short* __restrict__ packedb) {
+    fp16_saturate_mode();
     const int layer = blockIdx.y;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     const float* src = packed + PW_ATTN + (size_t)layer * AttnW::SIZE;

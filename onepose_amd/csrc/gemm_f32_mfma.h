@@ -423,19 +423,23 @@ __device__ __forceinline__ void bf16_split2(float a, float b, unsigned& hi, unsi
 // The same two-term idea on IEEE fp16 terms (GATSSPG_FLAG_PREC_FP16X3 / _FP16X4): x ~ x1 + x2 with x1 = RNE_fp16(x), x2 = RNE_fp16(x - x1):
 // 2 x 11 significand bits with signed remainders, i.e. a representation error <= 2^-23 |x| -- what rounding to fp32 itself costs is
 // 2^-24 -- as long as x2 stays a normal fp16 number (|x| >~ 0.06; below that the absolute error is the fp16 subnormal spacing,
-// 6e-8).  Both conversions are CLAMPED to +-65504 first (v_med3_f32): an out-of-range operand saturates (two terms reach
-// +-131008) instead of becoming infinity and then NaN.  (Round-toward-zero conversions, one instruction per pair and saturating
+// 6e-8).  Both conversions SATURATE at +-65504 (MODE.FP16_OVFL, below): an out-of-range operand gives two terms that reach
+// +-131008 instead of infinity and then NaN.  (Round-toward-zero conversions, one instruction per pair and saturating
 // by themselves, were measured first: the one-sided first term doubles the remainder and the mode kept a near-tie flip that the
 // RNE form does not have in the four-product mode -- tests/studies/split_bf16_study.py.)
 //   fp16x3: a1 b1 + a1 b2 + a2 b1              three v_mfma_f32_32x32x16_f16 per 32x32x16 block: the matrix-pipe time of bf16x3
 //   fp16x4: + a2 b2 (first, smallest)          four: the exact product of the split operands -- fp32-class
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// MODE.FP16_OVFL (hwreg 1, bit 23): an overflowing fp16 RESULT is clamped to +-65504 instead of becoming infinity.  Set once per wave
+// by every kernel that splits into fp16 terms (checked on the GPU: 1e5 -> 65504 + 34496, -3e38 -> -65504 - 65504); it replaces four
+// v_med3_f32 per operand pair in the main loops (measured with the explicit clamps: mlp0 +1.5 us).
+__device__ __forceinline__ void fp16_saturate_mode() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }
+// requires fp16_saturate_mode() earlier in the wave
 __device__ __forceinline__ void fp16_split2(float a, float b, unsigned& hi, unsigned& lo) {
-    const f32x2 ac = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
-    const f16x2 h = __builtin_convertvector(ac, f16x2);
+    const f16x2 h = __builtin_convertvector((f32x2){a, b}, f16x2);
     hi = __builtin_bit_cast(unsigned, h);
-    const f32x2 r = {__builtin_amdgcn_fmed3f(a - (float)h[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b - (float)h[1], -65504.f, 65504.f)};
+    const f32x2 r = {a - (float)h[0], b - (float)h[1]};
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 

@@ -609,6 +609,33 @@ def test_instance_norm_is_robust_to_large_channel_means():
     assert e2 < 1e-4 and e3 < 1e-4, (e2, e3)
 
 
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16x4"])
+def test_fp16_terms_saturate_instead_of_overflowing(precision):
+    """Operands beyond the fp16 range (state values of +-3e5 and 1e30 here: descriptors scaled up before an attention layer) must
+    give finite results in the fp16-split modes: the conversions saturate at +-65504 (MODE.FP16_OVFL), they never produce the
+    infinity that a plain fp16 conversion would turn into NaN.  Up to +-131008 the two terms still represent the operand, so a
+    state scaled to +-1e5 must also stay CLOSE to the fp32 arithmetic (InstanceNorm makes the layer scale-invariant enough)."""
+    sd = synthetic.make_state_dict(0)
+    data = synthetic.make_inputs(b=1, n1=200, n2=600, num_leaf=8, seed=91)
+    x, y = data["descriptors2d_query"], data["descriptors3d_db"]
+    outs = {}
+    for scale in (3e5, 1e30):
+        for prec in ("fp32", precision):
+            eng = make_model(sd, HP, prec).engine
+            dims = eng.load_state(torch.from_numpy(x * np.float32(scale)).to(dev()), torch.from_numpy(y * np.float32(scale)).to(dev()), 8)
+            eng.attn_layer(dims, 0, _native.LAYER_SELF)
+            o2, o3 = eng.store_state(dims)
+            outs[(scale, prec)] = (o2.cpu().numpy(), o3.cpu().numpy())
+        o2, o3 = outs[(scale, precision)]
+        assert np.isfinite(o2).all() and np.isfinite(o3).all(), f"{precision}: non-finite output for operands of magnitude {scale:g}"
+    # descriptors are unit-norm with components ~0.06: x * 3e5 has components ~2e4 .. 1e5, inside the two-term range
+    r2, r3 = outs[(3e5, "fp32")]
+    o2, o3 = outs[(3e5, precision)]
+    rel = max(float(np.abs(o2 - r2).max() / np.abs(r2).max()), float(np.abs(o3 - r3).max() / np.abs(r3).max()))
+    print(f"{precision}: relative deviation from the fp32 arithmetic at operand magnitude ~1e5: {rel:.2e}")
+    assert rel < 1e-3
+
+
 @pytest.mark.parametrize("scale,n1,n2", [(0.005, 130, 1027), (0.002, 200, 520), (0.0124, 64, 96)])
 def test_tiny_scale_factor_takes_the_max_subtracting_softmax(scale, n1, n2):
     """1 / scale_factor > 80 would overflow exp() in the fused one-pass dual softmax; the reference accepts any value

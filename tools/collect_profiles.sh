@@ -8,7 +8,7 @@ cd $R
 python bench.py > $O/bench_headline.json 2> $O/bench_headline.err
 python bench.py --steps 20 --warmup 5 > $O/bench_headline_driver_protocol.json 2>/dev/null
 python bench.py --amortised --no-cpu-baseline --no-side-arithmetics > $O/bench_amortised.json 2>/dev/null
-for c in bf16x3 bf16x6 fp32-b8 bf16x3-b8 bf16x6-b8 real real-b8 stress stress-b4; do
+for c in bf16x3 bf16x6 fp16x3 fp16x4 fp32-b8 bf16x3-b8 bf16x6-b8 fp16x3-b8 fp16x4-b8 real real-b8 stress stress-b4; do
   steps=100; [[ $c == *b8* || $c == stress* ]] && steps=20
   python bench.py --config $c --steps $steps --warmup 5 --no-cpu-baseline > $O/bench_$c.json 2>/dev/null
 done
