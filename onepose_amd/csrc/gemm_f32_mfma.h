@@ -347,6 +347,8 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     // here (2, 8, 16 slabs); the body is branch-free and the step pair is unrolled so both register sets are
     // statically indexed (hipcc would otherwise sink the loads into a conditional block next to their use).
     const int KTL = ABLATE == 3 ? 2 : KT;
+    // (a static s_setprio 1 for the younger half of the workgroup -- the guide's two-waves-per-SIMD tip for attention loops -- was
+    //  A/B-timed here: 1234 -> 1187 frames/s in flight, 1024 -> 978 one at a time, mlp0 40.0 -> 42.7 us event-timed; not kept)
     for (int i = 0; i < KTL; i += 2) {
         if constexpr (T::KS == 2) step_ks(buf0, buf1, i, min(i + 3, last), ra0, rb0, rx0);
         else step(buf0, buf1, i, min(i + 3, last), ra0, rb0, rx0);
