@@ -407,7 +407,7 @@ def main_pipeline(args):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_spp_state_dict(0).items()}, strict=True)
     model = model.to(device).eval()
     images = [torch.from_numpy(synthetic.make_image(1, SPP_H, SPP_W, 11 + i)).to(device) for i in range(4)]
-    weights = Weights(device)
+    weights = Weights(device, args.matcher_precision)
     K, W, S = args.steps, args.warmup, max(1, args.streams)
     base = Runner(device, weights)
     slots = []
@@ -445,7 +445,7 @@ def main_pipeline(args):
                       "warmup": W, "ms_per_step": round(1e3 / thr, 4), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": f"{SPP_H}x{SPP_W} crop -> SuperPoint (top {N1}) -> GATsSPG vs N_3D={N2} database -> RANSAC-EPnP "
                                              f"({pnp.ITERATIONS} hypotheses), batch 1, all hand-offs in HBM", "frames_in_flight": S,
-                                 "matches_into_pnp": n_matches,
+                                 "matches_into_pnp": n_matches, "matcher_gemm_precision": args.matcher_precision,
                                  "single_frame_latency_ms": round(lat * 1e3, 4)}}), flush=True)
 
 
@@ -638,6 +638,8 @@ def main():
     ap.add_argument("--extractor", action="store_true", help="benchmark the SuperPoint extractor instead of the matcher")
     ap.add_argument("--spp-kernel", default="conv1b", choices=list(SPP_KERNEL_LAYERS))
     ap.add_argument("--pipeline", action="store_true", help="image -> extractor -> matcher, all hand-offs in HBM (informative)")
+    ap.add_argument("--matcher-precision", default="fp32", choices=list(_native.PRECISIONS),
+                    help="--pipeline: GEMM arithmetic of the matcher stage (fp32 = the reference's; fp16x4 / bf16x6 = fp32-class splits)")
     ap.add_argument("--torch-eager", action="store_true",
                     help="informative baseline: the reference algorithm through stock PyTorch-ROCm ops on this GPU")
     ap.add_argument("--pnp", action="store_true", help="benchmark the RANSAC-EPnP pose solver (informative)")
