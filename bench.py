@@ -229,6 +229,7 @@ class SppRunner:
     """One in-flight image slot of the extractor: own stream, workspace and outputs; step() = one spp_forward call."""
 
     def __init__(self, device, model, images, own_stream=False, b=1):
+        self.flags = model.engine.flags()
         self.lib = model.engine.lib
         self.packed = model.engine.packed_weights(device)
         self.cfg = model.config
@@ -247,7 +248,7 @@ class SppRunner:
         return (self.packed.data_ptr(), self.images[i % len(self.images)].data_ptr(), self.b, SPP_H, SPP_W, c["nms_radius"],
                 c["keypoint_threshold"], c["max_keypoints"], c["remove_borders"], 1, self.cap, self.kp.data_ptr(),
                 self.sc.data_ptr(), self.de.data_ptr(), self.cnt.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
-                self.stream.cuda_stream)
+                self.stream.cuda_stream, self.flags)
 
     def step(self, i):
         _native_spp.check(self.lib.spp_forward(*self._args(i)), "spp_forward")
@@ -276,7 +277,7 @@ def main_extractor(args):
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
-    model = SuperPoint(SPP_CFG)
+    model = SuperPoint(SPP_CFG, precision=args.extractor_precision)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_spp_state_dict(0).items()}, strict=True)
     model = model.to(device).eval()
     images = [torch.from_numpy(synthetic.make_image(1, SPP_H, SPP_W, 11 + i)).to(device) for i in range(4)]
@@ -322,9 +323,10 @@ def main_extractor(args):
         out = {
             "metric": "extractor_images_per_sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": round(seconds / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.extractor_precision == "fp32" else args.extractor_precision, "data": "synthetic",
             "config": {"workload": f"SuperPoint extractor (SURVEY 8(f) row 2), one synthetic {SPP_H}x{SPP_W} grayscale crop per step, "
-                                   "pipeline config nms_radius=3 max_keypoints=4096 threshold=0.005, fp32, random weights",
+                                   f"pipeline config nms_radius=3 max_keypoints=4096 threshold=0.005, GEMM convolutions {args.extractor_precision}, "
+                                   "random weights",
                        "images_in_flight_per_gpu": S, "single_image_latency_ms": round(latency * 1e3, 4),
                        "keypoints_out": n_kp, "algorithmic_gflop_per_image": round(total / 1e9, 2),
                        "end_to_end_f32_mfma_frac": round(total * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
@@ -403,7 +405,7 @@ def main_pipeline(args):
     from onepose_amd import _native_pnp, pnp
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
-    model = SuperPoint({**SPP_CFG, "max_keypoints": N1})
+    model = SuperPoint({**SPP_CFG, "max_keypoints": N1}, precision=args.extractor_precision)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_spp_state_dict(0).items()}, strict=True)
     model = model.to(device).eval()
     images = [torch.from_numpy(synthetic.make_image(1, SPP_H, SPP_W, 11 + i)).to(device) for i in range(4)]
@@ -446,6 +448,7 @@ def main_pipeline(args):
                       "config": {"workload": f"{SPP_H}x{SPP_W} crop -> SuperPoint (top {N1}) -> GATsSPG vs N_3D={N2} database -> RANSAC-EPnP "
                                              f"({pnp.ITERATIONS} hypotheses), batch 1, all hand-offs in HBM", "frames_in_flight": S,
                                  "matches_into_pnp": n_matches, "matcher_gemm_precision": args.matcher_precision,
+                                 "extractor_conv_precision": args.extractor_precision,
                                  "single_frame_latency_ms": round(lat * 1e3, 4)}}), flush=True)
 
 
@@ -638,6 +641,8 @@ def main():
     ap.add_argument("--extractor", action="store_true", help="benchmark the SuperPoint extractor instead of the matcher")
     ap.add_argument("--spp-kernel", default="conv1b", choices=list(SPP_KERNEL_LAYERS))
     ap.add_argument("--pipeline", action="store_true", help="image -> extractor -> matcher, all hand-offs in HBM (informative)")
+    ap.add_argument("--extractor-precision", default="fp32", choices=list(_native_spp.PRECISIONS),
+                    help="--extractor / --pipeline: arithmetic of the SuperPoint GEMM convolutions (fp32 = the reference's; fp16x4 = fp32-class split)")
     ap.add_argument("--matcher-precision", default="fp32", choices=list(_native.PRECISIONS),
                     help="--pipeline: GEMM arithmetic of the matcher stage (fp32 = the reference's; fp16x4 / bf16x6 = fp32-class splits)")
     ap.add_argument("--torch-eager", action="store_true",

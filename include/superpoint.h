@@ -43,11 +43,21 @@ typedef struct spp_raw_weights {
     const float* bias[SPP_NUM_LAYERS];
 } spp_raw_weights;
 
+/* Arithmetic of the GEMM convolutions (conv1b .. convDb), selected PER CALL by the `flags` argument of spp_dense / spp_forward
+ * (the library never reads the environment):
+ *   0 (default): exact fp32 MFMA (v_mfma_f32_32x32x2_f32) -- the reference's arithmetic;
+ *   SPP_FLAG_PREC_FP16X4: every fp32 operand as two fp16 terms (RNE, saturating at +-65504), all four products on
+ *     v_mfma_f32_32x32x16_f16 with fp32 accumulation -- fp32-class results at a quarter of the matrix-pipe time (the matcher's
+ *     GATSSPG_FLAG_PREC_FP16X4; include/gatsspg.h).  conv1a, the detector head's softmax, NMS / top-k and the descriptor sampling
+ *     are fp32 in both modes.  Unknown bits are refused. */
+#define SPP_FLAG_PREC_FP16X4 0x800
+
 int spp_version(void);
 const char* spp_last_error(void);
 
 /* One-time re-layout of the weights ([out][tap][in] K-order for the implicit-GEMM kernels, the two
- * 3x3 head convolutions stacked into one 512-row operator, rows padded to the tile height). */
+ * 3x3 head convolutions stacked into one 512-row operator, rows padded to the tile height), followed by the fp16 hi / lo
+ * planes of every GEMM convolution for SPP_FLAG_PREC_FP16X4 calls. */
 size_t spp_packed_weights_bytes(void);
 int spp_pack_weights(const spp_raw_weights* raw, float* packed, spp_stream_t stream);
 
@@ -56,7 +66,7 @@ size_t spp_workspace_bytes(int b, int H, int W);
 /* Dense stages (:142-162,183-184): image -> score_map [b][Hs][Ws] (cell softmax, dustbin dropped, 8x8
  * shuffle; BEFORE nms) and dense_desc [b][256][Hc][Wc] (convDb output, NOT normalised). */
 int spp_dense(const float* packed, const float* image, int b, int H, int W, float* score_map, float* dense_desc,
-              void* workspace, size_t workspace_bytes, spp_stream_t stream);
+              void* workspace, size_t workspace_bytes, spp_stream_t stream, int flags);
 
 /* Discrete stages (:163-195) from given dense tensors: NMS, threshold, border removal, top-k,
  * (h,w)->(x,y), descriptor normalisation + bilinear sampling + normalisation.
@@ -79,14 +89,14 @@ int spp_detect(const float* score_map, const float* dense_desc, int b, int H, in
 int spp_forward(const float* packed, const float* image, int b, int H, int W, int nms_radius, float keypoint_threshold,
                 int max_keypoints, int remove_borders, int align_corners, int capacity, float* keypoints,
                 float* scores, float* descriptors, int32_t* counts, void* workspace, size_t workspace_bytes,
-                spp_stream_t stream);
+                spp_stream_t stream, int flags);
 
 /* spp_forward with a HIP-event bracket around the `occurrence`-th launch of kernel `kernel_id`
  * (ids: onepose_amd/_native_spp.py::KERNEL_IDS) -- bench.py's per-kernel roofline timing. */
 int spp_forward_profiled(const float* packed, const float* image, int b, int H, int W, int nms_radius,
                          float keypoint_threshold, int max_keypoints, int remove_borders, int align_corners,
                          int capacity, float* keypoints, float* scores, float* descriptors, int32_t* counts,
-                         void* workspace, size_t workspace_bytes, spp_stream_t stream, int kernel_id, int occurrence,
+                         void* workspace, size_t workspace_bytes, spp_stream_t stream, int flags, int kernel_id, int occurrence,
                          spp_event_t ev_start, spp_event_t ev_stop);
 
 #ifdef __cplusplus

@@ -25,8 +25,11 @@ class RawWeights(ctypes.Structure):
     _fields_ = [("weight", c_void_p * NUM_LAYERS), ("bias", c_void_p * NUM_LAYERS)]
 
 
+FLAG_PREC_FP16X4 = 0x800
+PRECISIONS = {"fp32": 0, "fp16x4": FLAG_PREC_FP16X4}   # arithmetic of the GEMM convolutions, a `flags` bit per call
+
 _FWD = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-        c_void_p, c_void_p, c_size_t, c_void_p]
+        c_void_p, c_void_p, c_size_t, c_void_p, c_int]
 
 # name -> (restype, argtypes); every symbol include/superpoint.h declares
 SYMBOLS = {
@@ -35,7 +38,7 @@ SYMBOLS = {
     "spp_packed_weights_bytes": (c_size_t, []),
     "spp_pack_weights": (c_int, [POINTER(RawWeights), c_void_p, c_void_p]),
     "spp_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "spp_dense": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "spp_dense": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
     "spp_detect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p,
                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "spp_forward": (c_int, _FWD),

@@ -464,12 +464,14 @@ struct Bf3Layout {
 // F16: the two planes of each operand hold fp16 terms (fp16_split2) and the products run on v_mfma_f32_32x32x16_f16; layouts,
 // staging and pipeline are those of the bf16 form (16-bit elements either way).
 // NP = 4 (F16 only): the lo x lo product is kept as well (fp16x4).
+// BCol: tile column -> element offset from the B slab pointer (identity, or the image-patch map of the SuperPoint convolutions; the B
+// loads of this loop are dword loads, so column-shifted / 4-byte-aligned views (T::BU) need nothing else).
 template <class T, class AHi, class ALo, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, class Hooks = NoHooks,
-          bool F16 = false, int NP = 3>
+          bool F16 = false, int NP = 3, class BCol = IdentityCol>
 __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, AHi a_hi, ALo a_lo,
                                                      int lda, BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform,
-                                                     Hooks* hooks = nullptr) {
-    static_assert(!T::AKM && !T::BU, "row-major A, aligned B");
+                                                     Hooks* hooks = nullptr, BCol bcolmap = BCol()) {
+    static_assert(!T::AKM, "row-major A");
     using LY = Bf3Layout<T>;
     if constexpr (Hooks::ENABLED)
         static_assert(T::BN == 64 && T::THREADS == 512 && T::TM == 1 && T::TN == 1 && LY::KPT == 4, "fold hooks: 64-column tile, 8 waves");
@@ -487,12 +489,18 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
         a_goff[p] = 2u * (unsigned)(r * lda + c8 * 8);
         a_soff[p] = r * KS + c8 * 8;
     }
+    // plane (hi / lo) of A piece p: a compile-time constant when a plane is a whole number of thread rounds; with more threads than
+    // pieces per plane (64-row tile on 8 waves) the waves split between the planes (wave-uniform)
+    auto a_plane_lo = [&](int p) -> bool {
+        if constexpr ((BM * 4) % T::THREADS == 0) return (p * T::THREADS) / (BM * 4) != 0;
+        else return __builtin_amdgcn_readfirstlane((p * T::THREADS + tid) / (BM * 4)) != 0;
+    };
     // B: one column, KPT consecutive k; the k group is wave-uniform (BN is a multiple of 64)
     const int bcol = tid % BN;
     const int k0 = __builtin_amdgcn_readfirstlane(tid / BN) * KPT;
     unsigned b_goff[KPT];
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) b_goff[j] = 4u * (unsigned)((k0 + j) * ldb + bcol);
+    for (int j = 0; j < KPT; ++j) b_goff[j] = 4u * (unsigned)((k0 + j) * ldb + bcolmap(bcol));
     const int b_soff = bcol * KS + k0;
 
     u32x4 ra0[AP], ra1[AP];
@@ -501,7 +509,7 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
     auto gload = [&](int kt, u32x4(&ra)[AP], float(&rb)[KPT], float2(&rx)[KPT]) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            const bool lo = (p * T::THREADS) / (BM * 4) != 0;
+            const bool lo = a_plane_lo(p);
             const unsigned short* base = lo ? a_lo(kt) : a_hi(kt);
             ra[p] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + a_goff[p]);
         }
@@ -519,7 +527,7 @@ __device__ __forceinline__ void gemm_mainloop_bf3_ex(f32x16 (&acc)[T::TM][T::TN]
         }
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            const bool lo = (p * T::THREADS) / (BM * 4) != 0;
+            const bool lo = a_plane_lo(p);
             *reinterpret_cast<u32x4*>(stage + (lo ? LY::A_PLANE : 0) + a_soff[p]) = ra[p];
         }
         unsigned short* Bhi = stage + 2 * LY::A_PLANE;
@@ -819,12 +827,12 @@ __device__ __forceinline__ void gemm_mainloop_bf6_ex(f32x16 (&acc)[T::TM][T::TN]
 struct NoXform1 {
     __device__ __forceinline__ float operator()(float v, float2) const { return v; }
 };
-template <class T, class AHi, class ALo, class BSlab, class Hooks = NoHooks, bool F16 = false, int NP = 3>
+template <class T, class AHi, class ALo, class BSlab, class Hooks = NoHooks, bool F16 = false, int NP = 3, class BCol = IdentityCol>
 __device__ __forceinline__ void gemm_mainloop_bf3(f32x16 (&acc)[T::TM][T::TN], unsigned short* smem, int KT, AHi a_hi, ALo a_lo,
-                                                  int lda, BSlab b_slab, int ldb, Hooks* hooks = nullptr) {
+                                                  int lda, BSlab b_slab, int ldb, Hooks* hooks = nullptr, BCol bcolmap = BCol()) {
     auto nox = [](int) { return static_cast<const float*>(nullptr); };
-    gemm_mainloop_bf3_ex<T, AHi, ALo, BSlab, decltype(nox), decltype(nox), NoXform1, false, Hooks, F16, NP>(
-        acc, smem, KT, a_hi, a_lo, lda, b_slab, ldb, nox, nox, NoXform1(), hooks);
+    gemm_mainloop_bf3_ex<T, AHi, ALo, BSlab, decltype(nox), decltype(nox), NoXform1, false, Hooks, F16, NP, BCol>(
+        acc, smem, KT, a_hi, a_lo, lda, b_slab, ldb, nox, nox, NoXform1(), hooks, bcolmap);
 }
 
 template <class T, class APlane, class BSlab, class Hooks = NoHooks>

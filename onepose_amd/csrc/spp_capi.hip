@@ -63,11 +63,18 @@ DescView padded_view(const Workspace& w) {
     return v;
 }
 
+int check_flags(int flags, Workspace& w) {
+    if (flags & ~SPP_FLAG_PREC_FP16X4) return fail("unknown bits in flags (0x%x)", flags);
+    w.prec = (flags & SPP_FLAG_PREC_FP16X4) ? 4 : 0;
+    return 0;
+}
+
 int forward_impl(const float* packed, const float* image, int b, int H, int W, int nms_radius, float thr, int max_keypoints,
                  int remove_borders, int align_corners, int capacity, float* keypoints, float* scores, float* descriptors,
-                 int32_t* counts, void* ws, size_t ws_bytes, void* stream, ProfileHook* hk) {
+                 int32_t* counts, void* ws, size_t ws_bytes, void* stream, int flags, ProfileHook* hk) {
     Workspace w;
     if (int e = check_ws(ws, ws_bytes, b, H, W, w)) return e;
+    if (int e = check_flags(flags, w)) return e;
     DetectParams dp;
     if (int e = check_detect(nms_radius, max_keypoints, remove_borders, capacity, dp, thr, align_corners)) return e;
     if (!packed || !image || !keypoints || !scores || !descriptors || !counts) return fail("null argument");
@@ -81,10 +88,10 @@ int forward_impl(const float* packed, const float* image, int b, int H, int W, i
 
 extern "C" {
 
-int spp_version(void) { return 1; }
+int spp_version(void) { return 2; }   // 2: `flags` argument (convolution arithmetic), fp16 weight planes in the packed blob
 const char* spp_last_error(void) { return g_err; }
 
-size_t spp_packed_weights_bytes(void) { return sizeof(float) * PW_TOTAL; }
+size_t spp_packed_weights_bytes(void) { return PACKED_BYTES; }
 
 int spp_pack_weights(const spp_raw_weights* raw, float* packed, spp_stream_t stream) {
     if (!raw || !packed) return fail("null argument");
@@ -100,9 +107,10 @@ size_t spp_workspace_bytes(int b, int H, int W) {
 }
 
 int spp_dense(const float* packed, const float* image, int b, int H, int W, float* score_map, float* dense_desc, void* workspace,
-              size_t workspace_bytes, spp_stream_t stream) {
+              size_t workspace_bytes, spp_stream_t stream, int flags) {
     Workspace w;
     if (int e = check_ws(workspace, workspace_bytes, b, H, W, w)) return e;
+    if (int e = check_flags(flags, w)) return e;
     if (!packed || !image || !score_map || !dense_desc) return fail("null argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     launch_dense(packed, image, w, s, nullptr);
@@ -130,15 +138,15 @@ int spp_detect(const float* score_map, const float* dense_desc, int b, int H, in
 
 int spp_forward(const float* packed, const float* image, int b, int H, int W, int nms_radius, float keypoint_threshold,
                 int max_keypoints, int remove_borders, int align_corners, int capacity, float* keypoints, float* scores,
-                float* descriptors, int32_t* counts, void* workspace, size_t workspace_bytes, spp_stream_t stream) {
+                float* descriptors, int32_t* counts, void* workspace, size_t workspace_bytes, spp_stream_t stream, int flags) {
     return forward_impl(packed, image, b, H, W, nms_radius, keypoint_threshold, max_keypoints, remove_borders, align_corners,
-                        capacity, keypoints, scores, descriptors, counts, workspace, workspace_bytes, stream, nullptr);
+                        capacity, keypoints, scores, descriptors, counts, workspace, workspace_bytes, stream, flags, nullptr);
 }
 
 int spp_forward_profiled(const float* packed, const float* image, int b, int H, int W, int nms_radius, float keypoint_threshold,
                          int max_keypoints, int remove_borders, int align_corners, int capacity, float* keypoints,
                          float* scores, float* descriptors, int32_t* counts, void* workspace, size_t workspace_bytes,
-                         spp_stream_t stream, int kernel_id, int occurrence, spp_event_t ev_start, spp_event_t ev_stop) {
+                         spp_stream_t stream, int flags, int kernel_id, int occurrence, spp_event_t ev_start, spp_event_t ev_stop) {
     if (kernel_id < 0 || kernel_id >= KID_COUNT) return fail("kernel_id out of range");
     if (!ev_start || !ev_stop) return fail("null event");
     ProfileHook hk;
@@ -146,7 +154,7 @@ int spp_forward_profiled(const float* packed, const float* image, int b, int H, 
     hk.kernel_id = kernel_id; hk.occurrence = occurrence;
     hk.start = reinterpret_cast<hipEvent_t>(ev_start); hk.stop = reinterpret_cast<hipEvent_t>(ev_stop);
     return forward_impl(packed, image, b, H, W, nms_radius, keypoint_threshold, max_keypoints, remove_borders, align_corners,
-                        capacity, keypoints, scores, descriptors, counts, workspace, workspace_bytes, stream, &hk);
+                        capacity, keypoints, scores, descriptors, counts, workspace, workspace_bytes, stream, flags, &hk);
 }
 
 }  // extern "C"

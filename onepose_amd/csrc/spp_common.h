@@ -63,9 +63,21 @@ constexpr size_t conv_w_off(int i) {
 }
 constexpr size_t conv_b_off(int i) { return conv_w_off(i) + (size_t)kConv[i].rows * kConv[i].cin * kConv[i].taps; }
 constexpr size_t PW_TOTAL = conv_w_off(NGEMM);
+// fp16 hi / lo planes of the GEMM convolutions' weights (SPP_FLAG_PREC_FP16X4): appended to the fp32 blob, in 16-bit elements from
+// (unsigned short*)(packed + PW_TOTAL).  w = hi + lo with hi = RNE_fp16(w), lo = RNE_fp16(w - hi); per convolution the hi plane
+// then the lo plane, each slab-major: element (m, k) of the [rows][K] operator at ((k / 32) * rows + m) * 32 + k % 32.
+constexpr size_t conv_k(int i) { return (size_t)kConv[i].cin * kConv[i].taps; }
+constexpr size_t conv_wp_off(int i) {
+    size_t o = 0;
+    for (int j = 0; j < i; ++j) o += 2 * (size_t)kConv[j].rows * conv_k(j);
+    return o;
+}
+constexpr size_t PWP_TOTAL = conv_wp_off(NGEMM);                                  // 16-bit elements
+constexpr size_t PACKED_BYTES = sizeof(float) * PW_TOTAL + sizeof(unsigned short) * PWP_TOTAL;
 
 // ---- workspace ---------------------------------------------------------------------------------------------
 struct Workspace {
+    int prec;                        // 0: fp32 MFMA convolutions; 4: four-term split-fp16 (SPP_FLAG_PREC_FP16X4), from the call's flags
     FeatLayout L1, L2, L3, L4;       // full, 1/2, 1/4, 1/8 resolution
     float *a1, *b1, *a2, *b2, *a3, *b3, *c3, *a4, *b4, *hd, *lg, *dd;
     float *score, *nms, *invn;
@@ -78,6 +90,7 @@ inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
 inline Workspace carve_workspace(void* base, int b, int H, int W) {
     Workspace w;
+    w.prec = 0;
     w.L1 = make_feat_layout(b, H, W);
     w.L2 = make_feat_layout(b, H / 2, W / 2);
     w.L3 = make_feat_layout(b, H / 4, W / 4);

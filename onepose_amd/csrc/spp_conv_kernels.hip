@@ -19,8 +19,17 @@ using gatsspg::f32x16;
 using gatsspg::GemmTile;
 using gatsspg::mfma_row;
 
-template <class T>
-constexpr size_t smem_bytes() { return sizeof(float) * T::SMEM_FLOATS; }
+// PREC: 0 = fp32 MFMA main loop; 4 = four-term split-fp16 (gemm_mainloop_bf3, F16, NP = 4: two fp16 terms per operand, all four
+// products on v_mfma_f32_32x32x16_f16 -- fp32-class results, a quarter of the matrix-pipe time; weights pre-split at pack time,
+// activations split in the loop)
+template <class T, int PREC = 0>
+constexpr size_t smem_bytes() {
+    size_t b = sizeof(float) * T::SMEM_FLOATS;
+    if constexpr (PREC == 4) {
+        if (gatsspg::Bf3Layout<T>::SMEM_BYTES > b) b = gatsspg::Bf3Layout<T>::SMEM_BYTES;
+    }
+    return b;
+}
 
 // =====================================================================================================
 // conv1a + ReLU (:142): one thread per padded position, all 64 output channels
@@ -110,11 +119,13 @@ struct PatchCol {
     __device__ __forceinline__ int operator()(int c) const { return c < half ? c : c - half + Wp; }
 };
 
-template <class T, int CIN, int TAPS, bool PATCH>
+template <class T, int CIN, int TAPS, bool PATCH, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS) void conv_gemm_kernel(const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                               const unsigned short* __restrict__ Wp16, int rows,
                                                                const float* __restrict__ X, float* __restrict__ Y, FeatLayout L,
                                                                int cout, int relu) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (PREC == 4) gatsspg::fp16_saturate_mode();
     constexpr int CPS = CIN / BK;            // K slabs per tap
     constexpr int KT = TAPS * CPS;
     constexpr int HALF = T::BN / 2;
@@ -152,8 +163,22 @@ __global__ __launch_bounds__(T::THREADS) void conv_gemm_kernel(const float* __re
         const int shift = TAPS == 9 ? (tap / 3 - 1) * Wp + (tap % 3 - 1) : 0;
         return X + ((ptrdiff_t)cc * BK * ldt + c0 + shift);
     };
-    if constexpr (PATCH) gatsspg::gemm_mainloop<T, decltype(al), decltype(bl), 0, PatchCol>(acc, smem, KT, al, TAPS * CIN, bl, ldt, PatchCol{HALF, Wp});
-    else gatsspg::gemm_mainloop<T>(acc, smem, KT, al, TAPS * CIN, bl, ldt);
+    if constexpr (PREC == 4) {
+        // fp16 planes of the weights, slab-major [K/32][rows][32]: hi plane, then lo plane
+        const unsigned short* Ph = Wp16 + (size_t)rt * T::BM * BK;
+        const unsigned short* Pl = Ph + (size_t)rows * (TAPS * CIN);
+        auto ah = [&](int kt) { return Ph + (size_t)kt * rows * BK; };
+        auto alo = [&](int kt) { return Pl + (size_t)kt * rows * BK; };
+        unsigned short* sm16 = reinterpret_cast<unsigned short*>(smem);
+        if constexpr (PATCH)
+            gatsspg::gemm_mainloop_bf3<T, decltype(ah), decltype(alo), decltype(bl), gatsspg::NoHooks, true, 4, PatchCol>(
+                acc, sm16, KT, ah, alo, BK, bl, ldt, nullptr, PatchCol{HALF, Wp});
+        else
+            gatsspg::gemm_mainloop_bf3<T, decltype(ah), decltype(alo), decltype(bl), gatsspg::NoHooks, true, 4>(acc, sm16, KT, ah, alo, BK, bl, ldt);
+    } else {
+        if constexpr (PATCH) gatsspg::gemm_mainloop<T, decltype(al), decltype(bl), 0, PatchCol>(acc, smem, KT, al, TAPS * CIN, bl, ldt, PatchCol{HALF, Wp});
+        else gatsspg::gemm_mainloop<T>(acc, smem, KT, al, TAPS * CIN, bl, ldt);
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
@@ -193,12 +218,14 @@ __global__ __launch_bounds__(T::THREADS) void conv_gemm_kernel(const float* __re
 // written (conv1b: 67.7 MB less HBM traffic, one launch less per resolution).  Y2 is the half-resolution padded plane;
 // only its pixels are written (its pad ring is zeroed once per forward by conv1a_kernel's extra workgroups).
 // =====================================================================================================
-template <class T, int CIN>
+template <class T, int CIN, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS) void conv_pool_kernel(const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                               const unsigned short* __restrict__ Wp16, int rows,
                                                                const float* __restrict__ X, float* __restrict__ Y2, FeatLayout L,
                                                                FeatLayout L2, int cout) {
     static_assert(T::BN == 128 && T::BM == 64, "2 x 64 pixel patch, 64 output channels per workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (PREC == 4) gatsspg::fp16_saturate_mode();
     constexpr int CPS = CIN / BK, KT = 9 * CPS;
     static_assert(KT % 2 == 0, "the main loop consumes slabs in pairs");
     const int SEG = (L.W + 63) / 64, HP = L.H / 2;
@@ -220,7 +247,16 @@ __global__ __launch_bounds__(T::THREADS) void conv_pool_kernel(const float* __re
         const int tap = kt / CPS, cc = kt - tap * CPS;
         return X + ((ptrdiff_t)cc * BK * ldt + c0 + (tap / 3 - 1) * Wp + (tap % 3 - 1));
     };
-    gatsspg::gemm_mainloop<T, decltype(al), decltype(bl), 0, PatchCol>(acc, smem, KT, al, 9 * CIN, bl, ldt, PatchCol{64, Wp});
+    if constexpr (PREC == 4) {
+        const unsigned short* Ph = Wp16 + (size_t)rt * T::BM * BK;
+        const unsigned short* Pl = Ph + (size_t)rows * (9 * CIN);
+        auto ah = [&](int kt) { return Ph + (size_t)kt * rows * BK; };
+        auto alo = [&](int kt) { return Pl + (size_t)kt * rows * BK; };
+        gatsspg::gemm_mainloop_bf3<T, decltype(ah), decltype(alo), decltype(bl), gatsspg::NoHooks, true, 4, PatchCol>(
+            acc, reinterpret_cast<unsigned short*>(smem), KT, ah, alo, BK, bl, ldt, nullptr, PatchCol{64, Wp});
+    } else {
+        gatsspg::gemm_mainloop<T, decltype(al), decltype(bl), 0, PatchCol>(acc, smem, KT, al, 9 * CIN, bl, ldt, PatchCol{64, Wp});
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
@@ -291,6 +327,21 @@ __global__ void pack_conv_kernel(const float* __restrict__ src, const float* __r
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cout; i += gridDim.x * blockDim.x) bdst[row0 + i] = bsrc[i];
 }
 
+// fp16 hi / lo planes of one GEMM convolution's packed weights (slab-major, spp_common.h)
+__global__ __launch_bounds__(256) void split_conv_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, int rows,
+                                                                 int K) {
+    gatsspg::fp16_saturate_mode();
+    const size_t n = (size_t)rows * K;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / K, k = i % K;
+        unsigned hi, lo;
+        gatsspg::fp16_split2(w[i], 0.f, hi, lo);
+        const size_t d = ((k >> 5) * rows + m) * 32 + (k & 31);
+        planes[d] = (unsigned short)(hi & 0xFFFFu);
+        planes[n + d] = (unsigned short)(lo & 0xFFFFu);
+    }
+}
+
 void launch_pack_weights(const void* raw_host, float* packed, hipStream_t s) {
     const spp_raw_weights& r = *static_cast<const spp_raw_weights*>(raw_host);
     (void)hipMemsetAsync(packed, 0, sizeof(float) * PW_TOTAL, s);
@@ -308,6 +359,10 @@ void launch_pack_weights(const void* raw_host, float* packed, hipStream_t s) {
     pack(7, 10, 256);   // convDa
     pack(8, 9, 0);      // convPb
     pack(9, 11, 0);     // convDb
+    unsigned short* planes = reinterpret_cast<unsigned short*>(packed + PW_TOTAL);
+    for (int gi = 0; gi < NGEMM; ++gi)
+        hipLaunchKernelGGL(split_conv_weights_kernel, dim3(128), dim3(256), 0, s, packed + conv_w_off(gi), planes + conv_wp_off(gi),
+                           kConv[gi].rows, (int)conv_k(gi));
 }
 
 // =====================================================================================================
@@ -334,24 +389,25 @@ static bool patch_tiling() {
     return on;
 }
 
-template <class T, int CIN, int TAPS>
+template <class T, int CIN, int TAPS, int PREC>
 static void launch_conv_t(int gi, int kid, const float* packed, const float* X, float* Y, const FeatLayout& L, int relu,
                           hipStream_t s, ProfileHook* hk) {
     const int cout = kConv[gi].cout;
     const int MT = (cout + T::BM - 1) / T::BM;
+    const unsigned short* planes = reinterpret_cast<const unsigned short*>(packed + PW_TOTAL) + conv_wp_off(gi);
     if constexpr (TAPS == 9) {
         if (patch_tiling()) {
-            auto kern = conv_gemm_kernel<T, CIN, TAPS, true>;
+            auto kern = conv_gemm_kernel<T, CIN, TAPS, true, PREC>;
             const int NT = L.b * ((L.H + 1) / 2) * ((L.W + T::BN / 2 - 1) / (T::BN / 2));
-            SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(MT, NT)), dim3(T::THREADS), smem_bytes<T>(), s,
-                       packed + conv_w_off(gi), packed + conv_b_off(gi), X, Y, L, cout, relu);
+            SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(MT, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>()), s,
+                       packed + conv_w_off(gi), packed + conv_b_off(gi), planes, kConv[gi].rows, X, Y, L, cout, relu);
             return;
         }
     }
-    auto kern = conv_gemm_kernel<T, CIN, TAPS, false>;
+    auto kern = conv_gemm_kernel<T, CIN, TAPS, false, PREC>;
     const int NT = L.ldt / T::BN;
-    SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(MT, NT)), dim3(T::THREADS), smem_bytes<T>(), s, packed + conv_w_off(gi),
-               packed + conv_b_off(gi), X, Y, L, cout, relu);
+    SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(MT, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>()), s, packed + conv_w_off(gi),
+               packed + conv_b_off(gi), planes, kConv[gi].rows, X, Y, L, cout, relu);
 }
 
 // Tile shape per GEMM convolution: 0 = 64x128, 1 = 64x64, 2 = 128x64 (rows x columns), 3 = 64x128 on 8 waves,
@@ -375,13 +431,22 @@ static const int* conv_tiles() {
 
 template <int CIN, int TAPS>
 static void launch_conv(int gi, int kid, const float* packed, const float* X, float* Y, const FeatLayout& L, int relu,
-                        hipStream_t s, ProfileHook* hk) {
+                        hipStream_t s, ProfileHook* hk, int prec) {
+    if (prec == 4) {   // split-fp16 loop: a thread owns 4 or 8 k of one column -> the 64x128 tile runs on 8 waves
+        switch (conv_tiles()[gi]) {
+            case 0: case 3: launch_conv_t<Tile64x128w8, CIN, TAPS, 4>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+            case 2: launch_conv_t<Tile128x64, CIN, TAPS, 4>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+            case 4: launch_conv_t<Tile128x64w8, CIN, TAPS, 4>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+            default: launch_conv_t<Tile64x64, CIN, TAPS, 4>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+        }
+        return;
+    }
     switch (conv_tiles()[gi]) {
-        case 0: launch_conv_t<Tile64x128, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
-        case 2: launch_conv_t<Tile128x64, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
-        case 3: launch_conv_t<Tile64x128w8, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
-        case 4: launch_conv_t<Tile128x64w8, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
-        default: launch_conv_t<Tile64x64, CIN, TAPS>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+        case 0: launch_conv_t<Tile64x128, CIN, TAPS, 0>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+        case 2: launch_conv_t<Tile128x64, CIN, TAPS, 0>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+        case 3: launch_conv_t<Tile64x128w8, CIN, TAPS, 0>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+        case 4: launch_conv_t<Tile128x64w8, CIN, TAPS, 0>(gi, kid, packed, X, Y, L, relu, s, hk); break;
+        default: launch_conv_t<Tile64x64, CIN, TAPS, 0>(gi, kid, packed, X, Y, L, relu, s, hk); break;
     }
 }
 
@@ -393,38 +458,41 @@ static void launch_pool(const float* X, const FeatLayout& Li, float* Y, const Fe
 // conv + ReLU + 2x2 pool in one launch (SPP_FUSE_POOL=0 falls back to the two-kernel form for A/B timing)
 template <int CIN>
 static void launch_conv_pool(int gi, int kid, const float* packed, const float* X, float* tmp, float* Y2, const FeatLayout& L,
-                             const FeatLayout& L2, hipStream_t s, ProfileHook* hk) {
+                             const FeatLayout& L2, hipStream_t s, ProfileHook* hk, int prec) {
     static const bool fuse = !(tuning_env("SPP_FUSE_POOL") && atoi(tuning_env("SPP_FUSE_POOL")) == 0);
     const int cout = kConv[gi].cout;
     if (!fuse) {
-        launch_conv<CIN, 9>(gi, kid, packed, X, tmp, L, 1, s, hk);
+        launch_conv<CIN, 9>(gi, kid, packed, X, tmp, L, 1, s, hk, prec);
         launch_pool(tmp, L, Y2, L2, cout, s, hk);
         return;
     }
     static const bool w8 = tuning_env("SPP_POOL_TILE") && atoi(tuning_env("SPP_POOL_TILE")) == 1;   // 1: the 64x128 patch on 8 waves
     const int NT = L.b * (L.H / 2) * ((L.W + 63) / 64);
+    const unsigned short* planes = reinterpret_cast<const unsigned short*>(packed + PW_TOTAL) + conv_wp_off(gi);
     auto go = [&](auto kern, int threads, size_t lds) {
         SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(cout / 64, NT)), dim3(threads), lds, s, packed + conv_w_off(gi),
-                   packed + conv_b_off(gi), X, Y2, L, L2, cout);
+                   packed + conv_b_off(gi), planes, kConv[gi].rows, X, Y2, L, L2, cout);
     };
-    if (w8) go(conv_pool_kernel<Tile64x128w8, CIN>, Tile64x128w8::THREADS, smem_bytes<Tile64x128w8>());
-    else go(conv_pool_kernel<Tile64x128, CIN>, Tile64x128::THREADS, smem_bytes<Tile64x128>());
+    if (prec == 4) go(conv_pool_kernel<Tile64x128w8, CIN, 4>, Tile64x128w8::THREADS, smem_bytes<Tile64x128w8, 4>());
+    else if (w8) go(conv_pool_kernel<Tile64x128w8, CIN, 0>, Tile64x128w8::THREADS, smem_bytes<Tile64x128w8>());
+    else go(conv_pool_kernel<Tile64x128, CIN, 0>, Tile64x128::THREADS, smem_bytes<Tile64x128>());
 }
 
 void launch_dense(const float* packed, const float* image, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     PadPlanes pp{{w.a2, w.b2, w.a3, w.b3, w.a4, w.b4}, {w.L2, w.L2, w.L3, w.L3, w.L4, w.L4}, {64, 64, 64, 128, 128, 128}, 192};
     SPP_LAUNCH(hk, KID_CONV1A, s, conv1a_kernel, dim3((w.L1.ld + 255) / 256 + pp.nblocks, w.L1.b), dim3(256), 0, s, image,
                packed + PW_C1A_W, packed + PW_C1A_B, w.a1, w.L1, pp);
-    launch_conv_pool<64>(0, KID_CONV1B, packed, w.a1, w.b1, w.a2, w.L1, w.L2, s, hk);     // conv1b + pool
-    launch_conv<64, 9>(1, KID_CONV2, packed, w.a2, w.b2, w.L2, 1, s, hk);
-    launch_conv_pool<64>(2, KID_CONV2, packed, w.b2, w.a2, w.a3, w.L2, w.L3, s, hk);      // conv2b + pool (a2 is free: scratch)
-    launch_conv<64, 9>(3, KID_CONV3A, packed, w.a3, w.b3, w.L3, 1, s, hk);
-    launch_conv_pool<128>(4, KID_CONV3B, packed, w.b3, w.c3, w.a4, w.L3, w.L4, s, hk);    // conv3b + pool
-    launch_conv<128, 9>(5, KID_CONV4, packed, w.a4, w.b4, w.L4, 1, s, hk);
-    launch_conv<128, 9>(6, KID_CONV4, packed, w.b4, w.a4, w.L4, 1, s, hk);
-    launch_conv<128, 9>(7, KID_HEADS, packed, w.a4, w.hd, w.L4, 1, s, hk);                                  // relu(convPa), relu(convDa)
-    launch_conv<256, 1>(8, KID_CONVPB, packed, w.hd, w.lg, w.L4, 0, s, hk);                                 // logits
-    launch_conv<256, 1>(9, KID_CONVDB, packed, w.hd + (size_t)256 * w.L4.ldt, w.dd, w.L4, 0, s, hk);       // descriptors
+    const int pr = w.prec;
+    launch_conv_pool<64>(0, KID_CONV1B, packed, w.a1, w.b1, w.a2, w.L1, w.L2, s, hk, pr);     // conv1b + pool
+    launch_conv<64, 9>(1, KID_CONV2, packed, w.a2, w.b2, w.L2, 1, s, hk, pr);
+    launch_conv_pool<64>(2, KID_CONV2, packed, w.b2, w.a2, w.a3, w.L2, w.L3, s, hk, pr);      // conv2b + pool (a2 is free: scratch)
+    launch_conv<64, 9>(3, KID_CONV3A, packed, w.a3, w.b3, w.L3, 1, s, hk, pr);
+    launch_conv_pool<128>(4, KID_CONV3B, packed, w.b3, w.c3, w.a4, w.L3, w.L4, s, hk, pr);    // conv3b + pool
+    launch_conv<128, 9>(5, KID_CONV4, packed, w.a4, w.b4, w.L4, 1, s, hk, pr);
+    launch_conv<128, 9>(6, KID_CONV4, packed, w.b4, w.a4, w.L4, 1, s, hk, pr);
+    launch_conv<128, 9>(7, KID_HEADS, packed, w.a4, w.hd, w.L4, 1, s, hk, pr);                                  // relu(convPa), relu(convDa)
+    launch_conv<256, 1>(8, KID_CONVPB, packed, w.hd, w.lg, w.L4, 0, s, hk, pr);                                 // logits
+    launch_conv<256, 1>(9, KID_CONVDB, packed, w.hd + (size_t)256 * w.L4.ldt, w.dd, w.L4, 0, s, hk, pr);       // descriptors
 }
 
 void launch_export_dense(const Workspace& w, float* dense_desc, hipStream_t s) {

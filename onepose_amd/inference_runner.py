@@ -66,13 +66,13 @@ def read_image(path):
     return torch.from_numpy(g.astype(np.float32) / 255.0)[None, None]
 
 
-def load_models(paths, precision="fp32", device="cuda"):
+def load_models(paths, precision="fp32", device="cuda", extractor_precision="fp32"):
     """inference.py:49-77: the Lightning checkpoint's matcher + the SuperPoint weights (strict loads)."""
     from . import SuperPoint
     from .checkpoint import LitModelGATsSPG
     matcher = LitModelGATsSPG.load_from_checkpoint(paths["onepose_model_path"]).freeze().matcher
     matcher.precision = precision
-    extractor = SuperPoint({k: v for k, v in SPP_CONF.items() if k != "keypoints_threshold"}).eval()
+    extractor = SuperPoint({k: v for k, v in SPP_CONF.items() if k != "keypoints_threshold"}, precision=extractor_precision).eval()
     sd = torch.load(paths["extractor_model_path"], map_location="cpu")
     if isinstance(sd, dict):     # model_io.load_network unwraps 'net' (src/utils/model_io.py); Lightning files use 'state_dict'
         sd = sd.get("net", sd.get("state_dict", sd))
@@ -112,6 +112,7 @@ def main(argv=None):
     ap.add_argument("--data-dir", default="data")
     ap.add_argument("--objects", nargs="*", default=list(DEFAULT_OBJECTS), help="<object dir>:<sequence> pairs (test_GATsSPG.yaml input.data_dirs)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16x6", "fp16x3", "fp16x4"])
+    ap.add_argument("--extractor-precision", default="fp32", choices=["fp32", "fp16x4"], help="arithmetic of the SuperPoint GEMM convolutions")
     ap.add_argument("--num-leaf", type=int, default=8)
     ap.add_argument("--max-frames", type=int, default=None)
     ap.add_argument("--seed", type=int, default=12345,
@@ -129,13 +130,14 @@ def main(argv=None):
     if not torch.cuda.is_available():
         print("onepose_amd.inference_runner needs a ROCm GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         return 2
-    matcher, extractor = load_models(paths, a.precision)
+    matcher, extractor = load_models(paths, a.precision, extractor_precision=a.extractor_precision)
     for item in a.objects:
         obj, seq = item.split(":")
         res = inference_core(matcher, extractor, osp.join(paths["scan_data_dir"], obj, seq), osp.join(paths["sfm_model_dir"], obj),
                              a.num_leaf, a.max_frames)
         if res is not None:
-            print(json.dumps({"object": obj, "sequence": seq, "precision": a.precision, **res}), flush=True)
+            print(json.dumps({"object": obj, "sequence": seq, "precision": a.precision, "extractor_precision": a.extractor_precision, **res}),
+                  flush=True)
     return 0
 
 

@@ -94,6 +94,9 @@ class SuperPointEngine:
             self._ws[key] = ws
         return ws
 
+    def flags(self):
+        return _native_spp.PRECISIONS[self.module.precision]
+
     # ---- stages (tests) ----
     @_on_device
     def dense(self, image):
@@ -103,7 +106,7 @@ class SuperPointEngine:
         score = torch.empty(b, h // 8 * 8, w // 8 * 8, device=dev, dtype=torch.float32)
         dense = torch.empty(b, 256, h // 8, w // 8, device=dev, dtype=torch.float32)
         _native_spp.check(self.lib.spp_dense(self.packed_weights(dev).data_ptr(), image.data_ptr(), b, h, w, score.data_ptr(),
-                                             dense.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "spp_dense")
+                                             dense.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev), self.flags()), "spp_dense")
         return score, dense
 
     def _outputs(self, b, capacity, dev):
@@ -143,7 +146,7 @@ class SuperPointEngine:
         _native_spp.check(self.lib.spp_forward(
             self.packed_weights(dev).data_ptr(), image.data_ptr(), b, h, w, cfg["nms_radius"], cfg["keypoint_threshold"],
             cfg["max_keypoints"], cfg["remove_borders"], int(align_corners), cap, kp.data_ptr(), sc.data_ptr(), de.data_ptr(),
-            cnt.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "spp_forward")
+            cnt.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev), self.flags()), "spp_forward")
         return kp, sc, de, cnt
 
 
@@ -152,7 +155,12 @@ class SuperPoint(nn.Module):
 
     ``align_corners``: the reference picks it from ``int(torch.__version__[2]) > 2`` (:87) -- True on the torch
     1.x builds OnePose pins (its environment.yaml), which is the default here; pass False to reproduce what the
-    same line yields on torch >= 1.10 / 2.x."""
+    same line yields on torch >= 1.10 / 2.x.
+
+    ``precision`` (keyword, not part of the reference signature; also settable as an attribute): arithmetic of the GEMM
+    convolutions -- ``"fp32"`` (default: exact fp32 MFMA, the reference's arithmetic) or ``"fp16x4"`` (two fp16 terms per operand,
+    all four products: fp32-class results at a quarter of the matrix-pipe time; the matcher's mode of the same name).  It travels
+    to the library as a bit of the ``flags`` argument of the C ABI; nothing is read from the environment."""
 
     default_config = {
         "descriptor_dim": 256,
@@ -162,8 +170,9 @@ class SuperPoint(nn.Module):
         "remove_borders": 4,
     }
 
-    def __init__(self, config=None, align_corners=True):
+    def __init__(self, config=None, align_corners=True, precision="fp32"):
         super().__init__()
+        self.precision = precision
         self.config = {**self.default_config, **(config or {})}
         if self.config["descriptor_dim"] != 256:
             raise ValueError("onepose_amd.SuperPoint supports descriptor_dim=256 (the reference default and the matcher's input)")
@@ -174,6 +183,16 @@ class SuperPoint(nn.Module):
             raise ValueError('"max_keypoints" must be positive or "-1"')       # reference :135-137
         self.align_corners = bool(align_corners)
         self._engine = None
+
+    @property
+    def precision(self):
+        return self._precision
+
+    @precision.setter
+    def precision(self, value):
+        if value not in _native_spp.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_native_spp.PRECISIONS)} (got {value!r})")
+        self._precision = value
 
     @property
     def engine(self):

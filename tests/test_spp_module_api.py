@@ -64,8 +64,9 @@ def test_every_declared_symbol_is_exported():
         assert hasattr(lib, n), f"{n} declared in include/superpoint.h but not exported"
     assert set(names) == set(_native_spp.SYMBOLS)
     assert lib.spp_version() >= 1
-    assert lib.spp_packed_weights_bytes() == 4 * (64 * 9 + 64 + 64 + 3 * (64 * 576 + 64) + 128 * 576 + 128 + 3 * (128 * 1152 + 128)
-                                                  + 512 * 1152 + 512 + 128 * 256 + 128 + 256 * 256 + 256)
+    nw = 3 * 64 * 576 + 128 * 576 + 3 * 128 * 1152 + 512 * 1152 + 128 * 256 + 256 * 256           # GEMM-convolution weights
+    assert lib.spp_packed_weights_bytes() == (4 * (64 * 9 + 64 + 64 + nw + 3 * 64 + 4 * 128 + 512 + 128 + 256)   # fp32 blob
+                                              + 2 * 2 * nw)                                                       # + fp16 hi / lo planes
     assert 0 < lib.spp_workspace_bytes(1, 64, 64) < lib.spp_workspace_bytes(1, 512, 512) < 2**28
     assert lib.spp_workspace_bytes(1, 7, 64) == 0 and b">= 8" in lib.spp_last_error()
     assert lib.spp_workspace_bytes(1, 75, 101) > 0        # any size >= 8: floor-mode poolings like the reference
