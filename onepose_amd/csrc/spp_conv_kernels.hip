@@ -286,6 +286,200 @@ __global__ __launch_bounds__(T::THREADS) void conv_pool_kernel(const float* __re
 }
 
 // =====================================================================================================
+// conv1a + ReLU + conv1b + ReLU + MaxPool2d(2, 2) in ONE launch (split-fp16 arithmetic, SPP_FLAG_PREC_FP16X4; :142-145).
+// conv1b's B operand for a 2-row x 64-pixel output patch is the 64-channel conv1a activation on 4 rows x 66 pixels.  Instead of
+// reading it from HBM (conv1a_kernel writes 67.7 MB, the nine shifted views of conv1b re-read it: 590 MB of L2 -> L1 traffic,
+// which is what bounds the split-fp16 conv1b), the workgroup RECOMPUTES it from the 6 x 68 image pixels behind it -- 64 channels x
+// 264 positions x 9 FMAs, once per 32-channel slab -- applies ReLU, splits it into fp16 hi / lo terms ONCE (the shifted-view form
+// splits every element once per tap) and keeps the slab resident in LDS in the B-fragment image ([position][32 k], 80-byte rows).
+// A tap (dy, dx) is then an offset of dy * 66 + dx positions into that image; only the weight planes (8 KB per tap) stream through
+// the double-buffered A stages.  The conv1a values are the bits conv1a_kernel computes (same fmaf order, zeros outside the image).
+// Tile: 64 output channels x (2 rows x 64 pixels) on 8 waves, one 32x32 MFMA tile each, as conv_pool_kernel<Tile64x128w8>.
+// =====================================================================================================
+constexpr int C1_BW = 66, C1_COLS = 4 * C1_BW;        // resident block: 4 rows x 66 positions
+constexpr int C1_KS = 40;                             // 16-bit elements per LDS row (32 + 8 pad: conflict-free 16-byte fragment reads)
+constexpr int C1_A_PLANE = 64 * C1_KS, C1_A_STAGE = 2 * C1_A_PLANE;   // hi + lo planes of one tap's 64 x 32 weight slab
+constexpr int C1_B_PLANE = C1_COLS * C1_KS;
+// one A buffer of THREE tap slabs (a dy row of the 3x3 stencil): a step multiplies 24 MFMAs per wave between barriers instead of 8
+// (one tap per step, double-buffered: 83.5 us; the matrix-pipe floor of the four-term products is 31 us)
+constexpr size_t C1_SMEM_BYTES = 2 * (3 * (size_t)C1_A_STAGE + 2 * (size_t)C1_B_PLANE) + sizeof(float) * 6 * 68;
+static_assert(sizeof(float) * 64 * 132 <= 2 * (3 * (size_t)C1_A_STAGE + 2 * (size_t)C1_B_PLANE), "the pooling stage tile re-uses the operand buffers");
+
+__global__ __launch_bounds__(512) void conv1ab_pool_f16_kernel(const float* __restrict__ img, const float* __restrict__ w1a,
+                                                               const float* __restrict__ b1a, const unsigned short* __restrict__ Wp16,
+                                                               const float* __restrict__ bias, float* __restrict__ Y2, FeatLayout L,
+                                                               FeatLayout L2, int abl) {   // abl: timing ablations (tuning builds), 0 in the product
+    using gatsspg::u32x4;
+    using gatsspg::bf16x8;
+    using gatsspg::f16x8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gatsspg::fp16_saturate_mode();
+    unsigned short* const sm16 = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* const Abuf = sm16;                 // [3 taps][hi | lo][64][40]
+    unsigned short* const Bhi = sm16 + 3 * C1_A_STAGE;
+    unsigned short* const Blo = Bhi + C1_B_PLANE;
+    float* const patch = reinterpret_cast<float*>(Blo + C1_B_PLANE);   // [6][68] image pixels, zeros outside the image
+
+    const int SEG = (L.W + 63) / 64, HP = L.H / 2;
+    const int NT = L.b * HP * SEG;
+    const int per = (NT + 7) / 8;                      // XCD bands of consecutive patches (see conv_gemm_kernel)
+    const int slot = blockIdx.x >> 3;
+    const int t = (blockIdx.x & 7) * per + slot;
+    if (slot >= per || t >= NT) return;
+    const int im = t / (HP * SEG), r0 = t - im * (HP * SEG);
+    const int yp = r0 / SEG, sx = r0 - yp * SEG;       // pooled row, 64-pixel segment
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, half = lane >> 5, l31 = lane & 31;
+
+    // ---- weight planes of conv1b: slab-major [K/32][64][32], k = tap * 64 + ci -> slab of (tap, channel slab cc) = tap * 2 + cc;
+    //      the K loop runs cc-major (the resident block changes once): step st = cc * 9 + tap
+    constexpr int K1B = 9 * 64;
+    const int a_plane = __builtin_amdgcn_readfirstlane(tid >> 8);          // waves 0-3: hi plane, 4-7: lo plane
+    const int a_r = (tid & 255) >> 2, a_c8 = tid & 3;
+    const unsigned short* a_src = Wp16 + (size_t)a_plane * 64 * K1B + (size_t)a_r * 32 + a_c8 * 8;
+    const int a_soff = a_plane * C1_A_PLANE + a_r * C1_KS + a_c8 * 8;
+    // group grp = cc * 3 + (dy + 1): the three taps dx = -1, 0, 1 of one stencil row
+    auto gload_a = [&](int grp, u32x4 (&ra)[3]) {
+        const int cc = grp / 3, dyi = grp - cc * 3;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ra[d] = *reinterpret_cast<const u32x4*>(a_src + (size_t)(((dyi * 3 + d) * 2 + cc) * 64) * 32);
+    };
+    auto swrite_a = [&](const u32x4 (&ra)[3]) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) *reinterpret_cast<u32x4*>(Abuf + d * C1_A_STAGE + a_soff) = ra[d];
+    };
+
+    // ---- image patch: rows 2 yp - 2 .. 2 yp + 3, columns 64 sx - 2 .. 64 sx + 65
+    if (tid < 6 * 68) {
+        const int ri = tid / 68, xi = tid - ri * 68;
+        const int Y = 2 * yp - 2 + ri, X = 64 * sx - 2 + xi;
+        patch[tid] = (Y >= 0 && Y < L.H && X >= 0 && X < L.W) ? img[((size_t)im * L.H + Y) * L.W + X] : 0.f;
+    }
+    u32x4 ra[3];
+    gload_a(0, ra);
+    __syncthreads();
+
+    // ---- the resident block of channel slab cc: wave = (k group g = wave % 4 -> channels cc * 32 + 8 g .. + 7, column half wave / 4)
+    auto make_block = [&](int cc) {
+        const int g = __builtin_amdgcn_readfirstlane(wave & 3), colset = __builtin_amdgcn_readfirstlane(wave >> 2);
+        const int ch0 = cc * 32 + 8 * g;
+        float wgt[8][9], bs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bs[i] = b1a[ch0 + i];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) wgt[i][tp] = w1a[(ch0 + i) * 9 + tp];
+        }
+#pragma unroll
+        for (int rnd = 0; rnd < 3; ++rnd) {
+            const int jl = lane + 64 * rnd;                    // 132 columns per wave: two full rounds + 4 lanes
+            if (jl < 2 * C1_BW) {
+                const int j = colset * 2 * C1_BW + jl;
+                const int r = j / C1_BW, x = j - r * C1_BW;   // block row 0..3 (image row 2 yp - 1 + r), position 0..65 (column 64 sx - 1 + x)
+                const int Y = 2 * yp - 1 + r, X = 64 * sx - 1 + x;
+                const bool inside = Y >= 0 && Y < L.H && X >= 0 && X < L.W;
+                float v[9];
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) v[tp] = patch[(r + tp / 3) * 68 + x + tp % 3];
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    float a0 = bs[i], a1 = bs[i + 1];
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) {
+                        a0 = fmaf(wgt[i][tp], v[tp], a0);
+                        a1 = fmaf(wgt[i + 1][tp], v[tp], a1);
+                    }
+                    a0 = inside ? fmaxf(a0, 0.f) : 0.f;        // conv1a_kernel: ReLU, zeros at the pad positions of its plane
+                    a1 = inside ? fmaxf(a1, 0.f) : 0.f;
+                    gatsspg::fp16_split2(a0, a1, hi[i / 2], lo[i / 2]);
+                }
+                *reinterpret_cast<u32x4*>(Bhi + j * C1_KS + 8 * g) = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+                *reinterpret_cast<u32x4*>(Blo + j * C1_KS + 8 * g) = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+            }
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int arow = (wm * 32 + l31) * C1_KS;
+    const int ctile = wn * 32 + l31;                                       // tile column 0..127: patch row ctile / 64, pixel ctile % 64
+    const int jbase = ((ctile >> 6) + 1) * C1_BW + (ctile & 63) + 1;      // its position in the block for the centre tap
+    auto compute = [&](const unsigned short* A, int tap) {
+        const int jb = (jbase + (tap / 3 - 1) * C1_BW + (tap % 3 - 1)) * C1_KS;
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int ko = 16 * s2 + 8 * half;
+            ah[s2] = *reinterpret_cast<const bf16x8*>(A + arow + ko);
+            al[s2] = *reinterpret_cast<const bf16x8*>(A + C1_A_PLANE + arow + ko);
+            bh[s2] = *reinterpret_cast<const bf16x8*>(Bhi + jb + ko);
+            bl[s2] = *reinterpret_cast<const bf16x8*>(Blo + jb + ko);
+        }
+        auto h8 = [](bf16x8 v) { return __builtin_bit_cast(f16x8, v); };
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al[s2]), h8(bl[s2]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al[s2]), h8(bh[s2]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[s2]), h8(bl[s2]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[s2]), h8(bh[s2]), acc, 0, 0, 0);
+        }
+    };
+
+    if (!(abl & 1)) make_block(0);
+    swrite_a(ra);
+    gload_a(1, ra);
+    __syncthreads();
+    // group grp: 3 taps x 8 MFMAs from the A buffer; barrier (the buffer -- and after the last group of a channel slab the block --
+    // is free); the next group's slabs (in registers since the previous group) are written, the one after is requested; barrier.
+    for (int grp = 0; grp < 6; ++grp) {
+        const int dyi = grp % 3;
+        if (!(abl & 2)) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) compute(Abuf + d * C1_A_STAGE, dyi * 3 + d);
+        }
+        if (grp == 5) break;
+        __syncthreads();
+        if (grp == 2 && !(abl & 1)) make_block(1);
+        swrite_a(ra);
+        asm volatile("" ::: "memory");
+        if (!(abl & 4)) gload_a(min(grp + 2, 5), ra);
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- epilogue: bias + ReLU, 2x2 max over the 2 x 64 patch, pooled row out (as conv_pool_kernel)
+    if (abl & 8) {
+        if (acc[0] == 12345.f) Y2[0] = acc[1];
+        return;
+    }
+    constexpr int TS = 128 + 4;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int row = wm * 32 + mfma_row(rr, half);
+        smem[row * TS + wn * 32 + l31] = fmaxf(acc[rr] + bias[row], 0.f);
+    }
+    __syncthreads();
+    const int W2 = L.W / 2;
+    float* dst = Y2 + (size_t)im * L2.ld + (size_t)(yp + 1) * L2.Wp + 1 + 32 * sx;
+    for (int p = tid; p < 64 * 32; p += 512) {
+        const int ch = p >> 5, px = p & 31;
+        if (32 * sx + px < W2) {
+            const float* s0 = smem + ch * TS + 2 * px;
+            dst[(size_t)ch * L2.ldt + px] = fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[64], s0[65]));
+        }
+    }
+}
+
+// the pad rings of the patch-tiled planes, when conv1a_kernel (which carries this job in its spare workgroups) does not run
+__global__ __launch_bounds__(256) void zero_pad_rings_kernel(PadPlanes pp) {
+    const int worker = blockIdx.x * 256 + threadIdx.x, nworkers = gridDim.x * 256;
+#pragma unroll
+    for (int i = 0; i < PadPlanes::N; ++i) zero_pad_ring(pp.p[i], pp.L[i], pp.C[i], worker, nworkers);
+}
+
+// =====================================================================================================
 // MaxPool2d(2, 2) (:145,148,151) between padded planes; pad positions of the output are zeros
 // =====================================================================================================
 __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ X, FeatLayout Li, float* __restrict__ Y,
@@ -480,10 +674,29 @@ static void launch_conv_pool(int gi, int kid, const float* packed, const float* 
 
 void launch_dense(const float* packed, const float* image, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     PadPlanes pp{{w.a2, w.b2, w.a3, w.b3, w.a4, w.b4}, {w.L2, w.L2, w.L3, w.L3, w.L4, w.L4}, {64, 64, 64, 128, 128, 128}, 192};
-    SPP_LAUNCH(hk, KID_CONV1A, s, conv1a_kernel, dim3((w.L1.ld + 255) / 256 + pp.nblocks, w.L1.b), dim3(256), 0, s, image,
-               packed + PW_C1A_W, packed + PW_C1A_B, w.a1, w.L1, pp);
     const int pr = w.prec;
-    launch_conv_pool<64>(0, KID_CONV1B, packed, w.a1, w.b1, w.a2, w.L1, w.L2, s, hk, pr);     // conv1b + pool
+    static const int c1abl = tuning_env("SPP_C1_ABL") ? atoi(tuning_env("SPP_C1_ABL")) : 0;
+    static const bool fuse1 = !(tuning_env("SPP_FUSE_CONV1") && atoi(tuning_env("SPP_FUSE_CONV1")) == 0);   // 0: separate conv1a / conv1b (A/B timing)
+    if (pr == 4 && fuse1 && (w.L1.H & 1) == 0) {
+        // split-fp16: conv1a is recomputed inside conv1b's workgroups (its 64-channel full-resolution plane never exists)
+        static bool lds_ok[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !lds_ok[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1ab_pool_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)C1_SMEM_BYTES);
+            if (dev >= 0 && dev < 64) lds_ok[dev] = true;
+        }
+        SPP_LAUNCH(hk, KID_CONV1A, s, zero_pad_rings_kernel, dim3(pp.nblocks), dim3(256), 0, s, pp);
+        const int NT = w.L1.b * (w.L1.H / 2) * ((w.L1.W + 63) / 64);
+        SPP_LAUNCH(hk, KID_CONV1B, s, conv1ab_pool_f16_kernel, dim3(gatsspg::xcd_grid(1, NT)), dim3(512), C1_SMEM_BYTES, s, image,
+                   packed + PW_C1A_W, packed + PW_C1A_B, reinterpret_cast<const unsigned short*>(packed + PW_TOTAL) + conv_wp_off(0),
+                   packed + conv_b_off(0), w.a2, w.L1, w.L2, c1abl);
+    } else {
+        SPP_LAUNCH(hk, KID_CONV1A, s, conv1a_kernel, dim3((w.L1.ld + 255) / 256 + pp.nblocks, w.L1.b), dim3(256), 0, s, image,
+                   packed + PW_C1A_W, packed + PW_C1A_B, w.a1, w.L1, pp);
+        launch_conv_pool<64>(0, KID_CONV1B, packed, w.a1, w.b1, w.a2, w.L1, w.L2, s, hk, pr);     // conv1b + pool
+    }
     launch_conv<64, 9>(1, KID_CONV2, packed, w.a2, w.b2, w.L2, 1, s, hk, pr);
     launch_conv_pool<64>(2, KID_CONV2, packed, w.b2, w.a2, w.a3, w.L2, w.L3, s, hk, pr);      // conv2b + pool (a2 is free: scratch)
     launch_conv<64, 9>(3, KID_CONV3A, packed, w.a3, w.b3, w.L3, 1, s, hk, pr);
