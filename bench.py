@@ -336,6 +336,14 @@ def main_extractor(args):
                          "how": f"hipEvent pair on the compute stream around launch #0 of the {kernel} convolution in each of {K} "
                                 "steps of a one-image-at-a-time pass"},
         }
+        if args.extractor_precision == "fp16x4":
+            # four fp16 MFMA products per algorithmic one, priced against the dense 16-bit peak; the fp32-peak ratio stays beside it
+            rf = out["roofline"]
+            rf.update(achieved=round(4 * achieved, 2), peak=PEAK_BF16_MFMA_TFLOPS, frac=round(4 * achieved / PEAK_BF16_MFMA_TFLOPS, 4),
+                      flops_per_launch=4 * fl, algorithmic_tflops=round(achieved, 2),
+                      algorithmic_vs_f32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic("spp_" + kernel + "_fp16x4"))
+            if kernel == "conv1b":
+                rf["kernel"] = "conv1ab_pool_f16_kernel (conv1a recomputed + conv1b + ReLU + pool; conv1b's flops credited only)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = spp_cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -7,6 +7,7 @@
 //                     K = taps * Cin whose B slabs are column-shifted views (4-byte aligned loads).
 //   maxpool 2x2       streaming kernel between resolutions.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "gemm_f32_mfma.h"
 #include "spp_common.h"
@@ -289,50 +290,87 @@ __global__ __launch_bounds__(T::THREADS) void conv_pool_kernel(const float* __re
 // conv1a + ReLU + conv1b + ReLU + MaxPool2d(2, 2) in ONE launch (split-fp16 arithmetic, SPP_FLAG_PREC_FP16X4; :142-145).
 // conv1b's B operand for a 2-row x 64-pixel output patch is the 64-channel conv1a activation on 4 rows x 66 pixels.  Instead of
 // reading it from HBM (conv1a_kernel writes 67.7 MB, the nine shifted views of conv1b re-read it: 590 MB of L2 -> L1 traffic,
-// which is what bounds the split-fp16 conv1b), the workgroup RECOMPUTES it from the 6 x 68 image pixels behind it -- 64 channels x
-// 264 positions x 9 FMAs, once per 32-channel slab -- applies ReLU, splits it into fp16 hi / lo terms ONCE (the shifted-view form
-// splits every element once per tap) and keeps the slab resident in LDS in the B-fragment image ([position][32 k], 80-byte rows).
-// A tap (dy, dx) is then an offset of dy * 66 + dx positions into that image; only the weight planes (8 KB per tap) stream through
-// the double-buffered A stages.  The conv1a values are the bits conv1a_kernel computes (same fmaf order, zeros outside the image).
-// Tile: 64 output channels x (2 rows x 64 pixels) on 8 waves, one 32x32 MFMA tile each, as conv_pool_kernel<Tile64x128w8>.
+// which is what bounds the split-fp16 conv1b), the workgroup RECOMPUTES it from the 6 x 68 image pixels behind it -- on the matrix
+// pipe: [32 channels] x [16 k] . [16 k] x [32 positions] with k = the nine taps, the bias (against a column of ones) and zeros,
+// weights and pixels as two fp16 terms each, all four products, like conv1b itself -- applies ReLU, splits it into fp16 hi / lo
+// terms ONCE (the shifted-view form splits every element once per tap) and keeps the 32-channel slab resident in LDS in the
+// B-fragment image ([position][32 k], 80-byte rows).  A tap (dy, dx) is then an offset of dy * 66 + dx positions into that image;
+// only the weight planes (8 KB per tap, the same for every patch) stream through the A buffer, three taps (one stencil row) at a time.
+//
+// Schedule: persistent 512-thread workgroups, two per CU (78.9 KB of LDS each), each walking its XCD band of patches; a patch is
+// 12 barrier intervals, alternately STAGING and MULTIPLYING: [block 0] [24 MFMAs per wave] [A slabs 1] [MFMAs] [A slabs 2] [MFMAs]
+// [A slabs 3 + block 1] [MFMAs] [A slabs 4] [MFMAs] [A slabs 5, next pixels] [MFMAs] and, without a barrier, [A slabs 0 of the next
+// patch, epilogue from registers].  The accumulator chain of a 32x32 tile is serial, so a workgroup alone cannot overlap its
+// staging with its MFMAs; the CU does it with the other workgroup.  Measured with per-interval s_memtime stamps
+// (tools/conv1ab_probe.hip, profiles/r03k_*): a patch takes ~31 k cycles per workgroup = 18.4 k cycles of MFMA per SIMD for the two
+// workgroups' patches (59 % busy, shader clock 1.9 GHz under this load); multiply intervals 1750 + ~650 cycles at their barrier,
+// plain staging ~800, the block builds 2700-4300 (wave 0 builds two tiles), the epilogue ~2500.  Tried on the way, each measured
+// on the GPU: one tap per barrier, double-buffered (83 us); three fragment sets in flight (spills: a scratch reload on the way into
+// the epilogue or a block build is a memory round trip on the critical path); a start delay for the second wave of workgroups, to
+// put the two residents of a CU out of phase (`phase_delay`, no gain at any value: kept as a tuning knob at 0); ONE 1024-thread
+// workgroup whose halves run one barrier interval apart (89 us: every long staging interval stalls the other half at the shared
+// barrier); conv1a on the vector ALU (432 FMAs per thread and patch: as many VALU cycles as the MFMAs take, 82 us).
+// The epilogue needs no LDS and no barrier: a wave's 32 columns are 16 pixels of BOTH patch rows, so the 2x2 maximum is a
+// quad-permute (pixel pairs are neighbouring lanes) and a 16-lane swizzle (the rows), and the pooled values go to HBM from registers.
 // =====================================================================================================
+constexpr int C1_PHASE_DELAY = 0;                     // x 64 cycles of start delay for the second wave of workgroups (measured: no gain)
 constexpr int C1_BW = 66, C1_COLS = 4 * C1_BW;        // resident block: 4 rows x 66 positions
 constexpr int C1_KS = 40;                             // 16-bit elements per LDS row (32 + 8 pad: conflict-free 16-byte fragment reads)
 constexpr int C1_A_PLANE = 64 * C1_KS, C1_A_STAGE = 2 * C1_A_PLANE;   // hi + lo planes of one tap's 64 x 32 weight slab
 constexpr int C1_B_PLANE = C1_COLS * C1_KS;
-// one A buffer of THREE tap slabs (a dy row of the 3x3 stencil): a step multiplies 24 MFMAs per wave between barriers instead of 8
-// (one tap per step, double-buffered: 83.5 us; the matrix-pipe floor of the four-term products is 31 us)
-constexpr size_t C1_SMEM_BYTES = 2 * (3 * (size_t)C1_A_STAGE + 2 * (size_t)C1_B_PLANE) + sizeof(float) * 6 * 68;
-static_assert(sizeof(float) * 64 * 132 <= 2 * (3 * (size_t)C1_A_STAGE + 2 * (size_t)C1_B_PLANE), "the pooling stage tile re-uses the operand buffers");
+constexpr int C1_HALF_U16 = 3 * C1_A_STAGE + 2 * C1_B_PLANE + 2 * 6 * 68;   // A buffer (3 taps), block hi / lo, fp32 pixel patch
+constexpr int C1_SHARED_BYTES = 2 * 2 * 64 * 16 + 64 * 4;                   // conv1a's A fragments [2 slabs][hi | lo][64 lanes], conv1b's bias
+constexpr size_t C1_SMEM_BYTES = 2 * (size_t)C1_HALF_U16 + C1_SHARED_BYTES;
+static_assert(2 * C1_SMEM_BYTES <= 160 * 1024 && (2 * C1_HALF_U16) % 16 == 0, "two workgroups per CU");
 
-__global__ __launch_bounds__(512) void conv1ab_pool_f16_kernel(const float* __restrict__ img, const float* __restrict__ w1a,
-                                                               const float* __restrict__ b1a, const unsigned short* __restrict__ Wp16,
-                                                               const float* __restrict__ bias, float* __restrict__ Y2, FeatLayout L,
-                                                               FeatLayout L2, int abl) {   // abl: timing ablations (tuning builds), 0 in the product
+__global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* __restrict__ img, const float* __restrict__ w1a,
+                                                                const float* __restrict__ b1a, const unsigned short* __restrict__ Wp16,
+                                                                const float* __restrict__ bias, float* __restrict__ Y2, FeatLayout L,
+                                                                FeatLayout L2, PadPlanes pp, int phase_delay, int abl   // abl: timing ablations (tuning builds), 0 in the product
+#ifdef C1_PROBE
+                                                                ,
+                                                                unsigned long long* __restrict__ probe   // tools/conv1ab_probe.hip
+#endif
+) {
+#ifdef C1_PROBE
+    int probe_n = 0;
+#define C1_STAMP()                                                                                                   \
+    do {                                                                                                             \
+        if (blockIdx.x == 8 && (threadIdx.x & 511) == 0 && probe_n < 64)                                             \
+            probe[(threadIdx.x >> 9) * 64 + probe_n++] = __builtin_readcyclecounter();                               \
+    } while (0)
+#else
+#define C1_STAMP() ((void)0)
+#endif
     using gatsspg::u32x4;
     using gatsspg::bf16x8;
     using gatsspg::f16x8;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef C1_PROBE
+    if (blockIdx.x == 8 && threadIdx.x == 0) {
+        probe[128] = __builtin_readcyclecounter();
+        probe[130] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
     gatsspg::fp16_saturate_mode();
-    unsigned short* const sm16 = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* const sm16 = reinterpret_cast<unsigned short*>(smem_all);
     unsigned short* const Abuf = sm16;                 // [3 taps][hi | lo][64][40]
     unsigned short* const Bhi = sm16 + 3 * C1_A_STAGE;
     unsigned short* const Blo = Bhi + C1_B_PLANE;
     float* const patch = reinterpret_cast<float*>(Blo + C1_B_PLANE);   // [6][68] image pixels, zeros outside the image
+    gatsspg::u32x4* const wfrag = reinterpret_cast<gatsspg::u32x4*>(sm16 + C1_HALF_U16);
+    float* const bias_s = reinterpret_cast<float*>(wfrag + 2 * 2 * 64);
 
     const int SEG = (L.W + 63) / 64, HP = L.H / 2;
     const int NT = L.b * HP * SEG;
     const int per = (NT + 7) / 8;                      // XCD bands of consecutive patches (see conv_gemm_kernel)
-    const int slot = blockIdx.x >> 3;
-    const int t = (blockIdx.x & 7) * per + slot;
-    if (slot >= per || t >= NT) return;
-    const int im = t / (HP * SEG), r0 = t - im * (HP * SEG);
-    const int yp = r0 / SEG, sx = r0 - yp * SEG;       // pooled row, 64-pixel segment
+    const int nslots = gridDim.x >> 3;                 // workgroups per XCD; each walks its band with that stride
+    const int xcd = blockIdx.x & 7;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3, half = lane >> 5, l31 = lane & 31;
 
     // ---- weight planes of conv1b: slab-major [K/32][64][32], k = tap * 64 + ci -> slab of (tap, channel slab cc) = tap * 2 + cc;
-    //      the K loop runs cc-major (the resident block changes once): step st = cc * 9 + tap
+    //      the K loop runs cc-major (the resident block changes once per channel slab)
     constexpr int K1B = 9 * 64;
     const int a_plane = __builtin_amdgcn_readfirstlane(tid >> 8);          // waves 0-3: hi plane, 4-7: lo plane
     const int a_r = (tid & 255) >> 2, a_c8 = tid & 3;
@@ -349,134 +387,260 @@ __global__ __launch_bounds__(512) void conv1ab_pool_f16_kernel(const float* __re
         for (int d = 0; d < 3; ++d) *reinterpret_cast<u32x4*>(Abuf + d * C1_A_STAGE + a_soff) = ra[d];
     };
 
-    // ---- image patch: rows 2 yp - 2 .. 2 yp + 3, columns 64 sx - 2 .. 64 sx + 65
-    if (tid < 6 * 68) {
-        const int ri = tid / 68, xi = tid - ri * 68;
-        const int Y = 2 * yp - 2 + ri, X = 64 * sx - 2 + xi;
-        patch[tid] = (Y >= 0 && Y < L.H && X >= 0 && X < L.W) ? img[((size_t)im * L.H + Y) * L.W + X] : 0.f;
-    }
-    u32x4 ra[3];
-    gload_a(0, ra);
-    __syncthreads();
+    // ---- image patch of tile t: rows 2 yp - 2 .. 2 yp + 3, columns 64 sx - 2 .. 64 sx + 65 (one pixel per thread, tid < 408)
+    const int p_ri = tid / 68, p_xi = tid - p_ri * 68;
+    auto gload_patch = [&](int t, bool valid) -> float {
+        const int im = t / (HP * SEG), r0 = t - im * (HP * SEG);
+        const int yp = r0 / SEG, sx = r0 - yp * SEG;
+        const int Y = 2 * yp - 2 + p_ri, X = 64 * sx - 2 + p_xi;
+        return (valid && tid < 6 * 68 && Y >= 0 && Y < L.H && X >= 0 && X < L.W) ? img[((size_t)im * L.H + Y) * L.W + X] : 0.f;
+    };
 
-    // ---- the resident block of channel slab cc: wave = (k group g = wave % 4 -> channels cc * 32 + 8 g .. + 7, column half wave / 4)
-    auto make_block = [&](int cc) {
-        const int g = __builtin_amdgcn_readfirstlane(wave & 3), colset = __builtin_amdgcn_readfirstlane(wave >> 2);
-        const int ch0 = cc * 32 + 8 * g;
-        float wgt[8][9], bs[8];
+    // ---- conv1a on the matrix pipe.  A fragments per lane: row = channel l31 of the slab, k = 8 half .. + 7
+    auto load_w1a = [&](int cc, u32x4& whi, u32x4& wlo) {
+        const int ch = cc * 32 + l31;
+        float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            bs[i] = b1a[ch0 + i];
-#pragma unroll
-            for (int tp = 0; tp < 9; ++tp) wgt[i][tp] = w1a[(ch0 + i) * 9 + tp];
+        for (int i = 0; i < 8; ++i) v[i] = half ? 0.f : w1a[ch * 9 + i];
+        if (half) {
+            v[0] = w1a[ch * 9 + 8];
+            v[1] = b1a[ch];
         }
+        unsigned hi[4], lo[4];
 #pragma unroll
-        for (int rnd = 0; rnd < 3; ++rnd) {
-            const int jl = lane + 64 * rnd;                    // 132 columns per wave: two full rounds + 4 lanes
-            if (jl < 2 * C1_BW) {
-                const int j = colset * 2 * C1_BW + jl;
-                const int r = j / C1_BW, x = j - r * C1_BW;   // block row 0..3 (image row 2 yp - 1 + r), position 0..65 (column 64 sx - 1 + x)
-                const int Y = 2 * yp - 1 + r, X = 64 * sx - 1 + x;
-                const bool inside = Y >= 0 && Y < L.H && X >= 0 && X < L.W;
-                float v[9];
+        for (int i = 0; i < 4; ++i) gatsspg::fp16_split2(v[2 * i], v[2 * i + 1], hi[i], lo[i]);
+        whi = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+        wlo = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+    };
+    auto h8u = [](u32x4 v) { return __builtin_bit_cast(f16x8, v); };
+    // N 32-position tiles of the resident block at once (their dependency chains -- LDS, split, 4 MFMAs, split, LDS -- interleave):
+    // positions j = 32 tt + l31 -> block row j / 66 (image row 2 yp - 1 + r), x = j % 66
+    auto block_tiles = [&](auto ntag, const int (&tts)[2], int cc, int yp, int sx) {
+        constexpr int N = decltype(ntag)::value;
+        const u32x4 whi = wfrag[(cc * 2 + 0) * 64 + lane], wlo = wfrag[(cc * 2 + 1) * 64 + lane];
+        u32x4 phi[N], plo[N];
+        int jj[N];
 #pragma unroll
-                for (int tp = 0; tp < 9; ++tp) v[tp] = patch[(r + tp / 3) * 68 + x + tp % 3];
-                unsigned hi[4], lo[4];
+        for (int n = 0; n < N; ++n) {
+            int j = 32 * tts[n] + l31;
+            asm volatile("" : "+v"(j));                        // recompute the addresses here instead of keeping them alive across the K loop
+            jj[n] = j;
+            const int r = j / C1_BW, x = j - r * C1_BW;
+            const int Y = 2 * yp - 1 + r, X = 64 * sx - 1 + x;
+            const bool inside = j < C1_COLS && Y >= 0 && Y < L.H && X >= 0 && X < L.W;
+            const float* pp = patch + min(r, 3) * 68 + x;      // the 3 x 3 window's top-left pixel
+            float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; i += 2) {
-                    float a0 = bs[i], a1 = bs[i + 1];
+            for (int i = 0; i < 8; ++i) v[i] = pp[half ? (2 * 68 + 2) : ((i / 3) * 68 + i % 3)];
+            if (half) {
+                v[1] = 1.f;
 #pragma unroll
-                    for (int tp = 0; tp < 9; ++tp) {
-                        a0 = fmaf(wgt[i][tp], v[tp], a0);
-                        a1 = fmaf(wgt[i + 1][tp], v[tp], a1);
-                    }
-                    a0 = inside ? fmaxf(a0, 0.f) : 0.f;        // conv1a_kernel: ReLU, zeros at the pad positions of its plane
-                    a1 = inside ? fmaxf(a1, 0.f) : 0.f;
-                    gatsspg::fp16_split2(a0, a1, hi[i / 2], lo[i / 2]);
+                for (int i = 2; i < 8; ++i) v[i] = 0.f;
+            }
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                gatsspg::fp16_split2(v[2 * i], v[2 * i + 1], hi[i], lo[i]);
+                hi[i] = inside ? hi[i] : 0u;                   // conv1a_kernel: zeros at the pad positions of its plane (bias column included)
+                lo[i] = inside ? lo[i] : 0u;
+            }
+            phi[n] = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+            plo[n] = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+        }
+        f32x16 c[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) c[n][q] = 0.f;
+#pragma unroll
+        for (int n = 0; n < N; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8u(wlo), h8u(plo[n]), c[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < N; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8u(wlo), h8u(phi[n]), c[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < N; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8u(whi), h8u(plo[n]), c[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < N; ++n) c[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8u(whi), h8u(phi[n]), c[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            if (jj[n] < C1_COLS) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {                  // channels 8 g + 4 half .. + 3 of the slab = c[4 g .. 4 g + 3]
+                    unsigned h0, l0, h1, l1;
+                    gatsspg::fp16_split2(fmaxf(c[n][4 * g], 0.f), fmaxf(c[n][4 * g + 1], 0.f), h0, l0);
+                    gatsspg::fp16_split2(fmaxf(c[n][4 * g + 2], 0.f), fmaxf(c[n][4 * g + 3], 0.f), h1, l1);
+                    const int o = jj[n] * C1_KS + 8 * g + 4 * half;
+                    *reinterpret_cast<uint2*>(Bhi + o) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(Blo + o) = make_uint2(l0, l1);
                 }
-                *reinterpret_cast<u32x4*>(Bhi + j * C1_KS + 8 * g) = (u32x4){hi[0], hi[1], hi[2], hi[3]};
-                *reinterpret_cast<u32x4*>(Blo + j * C1_KS + 8 * g) = (u32x4){lo[0], lo[1], lo[2], lo[3]};
             }
         }
     };
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int arow = (wm * 32 + l31) * C1_KS;
-    const int ctile = wn * 32 + l31;                                       // tile column 0..127: patch row ctile / 64, pixel ctile % 64
-    const int jbase = ((ctile >> 6) + 1) * C1_BW + (ctile & 63) + 1;      // its position in the block for the centre tap
-    auto compute = [&](const unsigned short* A, int tap) {
-        const int jb = (jbase + (tap / 3 - 1) * C1_BW + (tap % 3 - 1)) * C1_KS;
-        bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int ko = 16 * s2 + 8 * half;
-            ah[s2] = *reinterpret_cast<const bf16x8*>(A + arow + ko);
-            al[s2] = *reinterpret_cast<const bf16x8*>(A + C1_A_PLANE + arow + ko);
-            bh[s2] = *reinterpret_cast<const bf16x8*>(Bhi + jb + ko);
-            bl[s2] = *reinterpret_cast<const bf16x8*>(Blo + jb + ko);
+    // 264 positions = 8 tiles of 32 + 8: wave w builds tile w, wave 0 also the tail
+    auto make_block = [&](int cc, int yp, int sx) {
+        C1_STAMP();
+        if (wave == 0) {
+            const int tts[2] = {0, 8};
+            block_tiles(std::integral_constant<int, 2>{}, tts, cc, yp, sx);
+        } else {
+            const int tts[2] = {wave, wave};
+            block_tiles(std::integral_constant<int, 1>{}, tts, cc, yp, sx);
         }
+        C1_STAMP();
+    };
+
+    const int arow = (wm * 32 + l31) * C1_KS;
+    // a wave's 32 columns: pixels 16 wn .. 16 wn + 15 of patch row l31 / 16 (the 2x2 pooling window stays inside the wave)
+    const int jbase = ((l31 >> 4) + 1) * C1_BW + 16 * wn + (l31 & 15) + 1;   // the column's position in the block for the centre tap
+    f32x16 acc;
+    // fragment sets (one 16-deep k step of a tap: A hi / lo, B hi / lo) are requested one to two steps ahead of the four MFMAs that
+    // consume them (two sets: a third one spills -- and a scratch reload on the way into the epilogue costs a memory round trip)
+    struct Frags {
+        bf16x8 ah, al, bh, bl;
+    };
+    auto lfrag = [&](Frags& f, int dyi, int hs) {          // hs = 2 * (dx + 1) + k step
+        const int d = hs >> 1, ko = 16 * (hs & 1) + 8 * half;
+        const unsigned short* A = Abuf + d * C1_A_STAGE + arow + ko;
+        const int jb = (jbase + (dyi - 1) * C1_BW + (d - 1)) * C1_KS + ko;
+        f.ah = *reinterpret_cast<const bf16x8*>(A);
+        f.al = *reinterpret_cast<const bf16x8*>(A + C1_A_PLANE);
+        f.bh = *reinterpret_cast<const bf16x8*>(Bhi + jb);
+        f.bl = *reinterpret_cast<const bf16x8*>(Blo + jb);
+    };
+    auto mm = [&](const Frags& f) {
         auto h8 = [](bf16x8 v) { return __builtin_bit_cast(f16x8, v); };
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(f.al), h8(f.bl), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(f.al), h8(f.bh), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(f.ah), h8(f.bl), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(f.ah), h8(f.bh), acc, 0, 0, 0);
+    };
+    auto compute3 = [&](int dyi) {
+        Frags f0, f1;
+        lfrag(f0, dyi, 0);
+        lfrag(f1, dyi, 1);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al[s2]), h8(bl[s2]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(al[s2]), h8(bh[s2]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[s2]), h8(bl[s2]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(ah[s2]), h8(bh[s2]), acc, 0, 0, 0);
+        for (int hs = 0; hs < 6; hs += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            mm(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (hs + 2 < 6) lfrag(f0, dyi, hs + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(f1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (hs + 3 < 6) lfrag(f1, dyi, hs + 3);
         }
     };
 
-    if (!(abl & 1)) make_block(0);
-    swrite_a(ra);
-    gload_a(1, ra);
-    __syncthreads();
-    // group grp: 3 taps x 8 MFMAs from the A buffer; barrier (the buffer -- and after the last group of a channel slab the block --
-    // is free); the next group's slabs (in registers since the previous group) are written, the one after is requested; barrier.
-    for (int grp = 0; grp < 6; ++grp) {
-        const int dyi = grp % 3;
-        if (!(abl & 2)) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) compute(Abuf + d * C1_A_STAGE, dyi * 3 + d);
+    // ---- epilogue of a finished patch, from registers: bias + ReLU, 2x2 max (pixel pairs = neighbouring lanes, rows = lanes 16 apart)
+    auto epilogue = [&](int t) {
+        if (abl & 8) {
+            if (acc[0] == 12345.f) Y2[0] = acc[1];
+            return;
         }
-        if (grp == 5) break;
-        __syncthreads();
-        if (grp == 2 && !(abl & 1)) make_block(1);
-        swrite_a(ra);
-        asm volatile("" ::: "memory");
-        if (!(abl & 4)) gload_a(min(grp + 2, 5), ra);
-        __syncthreads();
-    }
-    __syncthreads();
+        const int im = t / (HP * SEG), r0 = t - im * (HP * SEG);
+        const int yp = r0 / SEG, sx = r0 - yp * SEG;
+        int px2 = 8 * wn + ((l31 & 15) >> 1);              // pooled pixel of this lane's pair within the 32-pixel pooled segment
+        asm volatile("" : "+v"(px2));                      // (addresses recomputed here, not kept alive across the K loop)
+        float* dst = Y2 + (size_t)im * L2.ld + (size_t)(yp + 1) * L2.Wp + 1 + 32 * sx + px2;
+        const bool writer = (l31 & 17) == 0 && 32 * sx + px2 < L.W / 2;
+        float hmax[16];
+        int other[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bs = *reinterpret_cast<const float4*>(bias_s + wm * 32 + 8 * g + 4 * half);   // rows mfma_row(4 g .. 4 g + 3, half)
+            const float bb[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = fmaxf(acc[4 * g + q] + bb[q], 0.f);
+                hmax[4 * g + q] = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) other[r] = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, hmax[r]), 0x401F);   // lane ^ 16, all 16 in flight
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int row0 = wm * 32 + 8 * g + 4 * half;
+            asm volatile("" : "+v"(row0));
+            float* drow = dst + (size_t)row0 * L2.ldt;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (writer) drow[(size_t)q * L2.ldt] = fmaxf(hmax[4 * g + q], __builtin_bit_cast(float, other[4 * g + q]));
+        }
+    };
 
-    // ---- epilogue: bias + ReLU, 2x2 max over the 2 x 64 patch, pooled row out (as conv_pool_kernel)
-    if (abl & 8) {
-        if (acc[0] == 12345.f) Y2[0] = acc[1];
+    // the pad rings of the patch-tiled planes (conv1a_kernel carries this job in its spare workgroups when it runs): none of them is
+    // read here, and this kernel's own output plane gets pixels only.  Done after the patches (at the start it delays every
+    // workgroup's first patch: +4.6 us measured, against 5.8 us for a launch of its own).
+    auto zero_rings = [&]() {
+#pragma unroll
+        for (int i = 0; i < PadPlanes::N; ++i) zero_pad_ring(pp.p[i], pp.L[i], pp.C[i], blockIdx.x * 512 + threadIdx.x, gridDim.x * 512);
+    };
+    int slot = blockIdx.x >> 3;
+    if (slot >= per || xcd * per + slot >= NT) {
+        zero_rings();
         return;
     }
-    constexpr int TS = 128 + 4;
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-        const int row = wm * 32 + mfma_row(rr, half);
-        smem[row * TS + wn * 32 + l31] = fmaxf(acc[rr] + bias[row], 0.f);
+    u32x4 ra[3];
+    gload_a(0, ra);
+    int t = xcd * per + slot;
+    if (tid < 6 * 68) patch[tid] = gload_patch(t, true);
+    if (wave < 2) {                                        // conv1a's A fragments of both channel slabs
+        u32x4 whi, wlo;
+        load_w1a(wave, whi, wlo);
+        wfrag[(wave * 2 + 0) * 64 + lane] = whi;
+        wfrag[(wave * 2 + 1) * 64 + lane] = wlo;
     }
+    if (wave == 2) bias_s[lane] = bias[lane];
+    if (2 * slot >= nslots)                                // the workgroups that land beside the first wave of the grid (tuning knob, 0)
+        for (int i = 0; i < phase_delay; ++i) __builtin_amdgcn_s_sleep(1);
+    swrite_a(ra);                                          // group 0
     __syncthreads();
-    const int W2 = L.W / 2;
-    float* dst = Y2 + (size_t)im * L2.ld + (size_t)(yp + 1) * L2.Wp + 1 + 32 * sx;
-    for (int p = tid; p < 64 * 32; p += 512) {
-        const int ch = p >> 5, px = p & 31;
-        if (32 * sx + px < W2) {
-            const float* s0 = smem + ch * TS + 2 * px;
-            dst[(size_t)ch * L2.ldt + px] = fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[64], s0[65]));
-        }
-    }
-}
-
-// the pad rings of the patch-tiled planes, when conv1a_kernel (which carries this job in its spare workgroups) does not run
-__global__ __launch_bounds__(256) void zero_pad_rings_kernel(PadPlanes pp) {
-    const int worker = blockIdx.x * 256 + threadIdx.x, nworkers = gridDim.x * 256;
+    // The A slab registers are written to the buffer FIRST in every staging interval and re-requested LAST, so that they are not
+    // live across the block builds and the epilogue (the kernel sits at the 128-register limit of 4 waves per SIMD).
+    for (;;) {
+        const int im = t / (HP * SEG), r0 = t - im * (HP * SEG);
+        const int yp = r0 / SEG, sx = r0 - yp * SEG;       // pooled row, 64-pixel segment
+        const int nslot = slot + nslots;
+        const bool more = nslot < per && xcd * per + nslot < NT;
+        const float pix = gload_patch(xcd * per + nslot, more);   // the next patch's pixel: in flight until the staging interval after group 4
+        // interval 0: resident block of channel slab 0 (the A slabs of group 0 are in the buffer)
+        if (!(abl & 1)) make_block(0, yp, sx);
+        gload_a(1, ra);
 #pragma unroll
-    for (int i = 0; i < PadPlanes::N; ++i) zero_pad_ring(pp.p[i], pp.L[i], pp.C[i], worker, nworkers);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        C1_STAMP();
+        __syncthreads();
+        C1_STAMP();
+        // intervals 1..11: group grp = 3 taps x 8 MFMAs from the A buffer | the next group's slabs (in registers since the previous
+        // staging interval) are written, the one after is requested (after group 5 comes group 0 of the next patch)
+        for (int grp = 0; grp < 6; ++grp) {
+            if (!(abl & 2)) compute3(grp % 3);
+            C1_STAMP();
+            __syncthreads();
+            C1_STAMP();
+            if (grp == 5) break;
+            swrite_a(ra);
+            asm volatile("" ::: "memory");
+            if (grp == 2 && !(abl & 1)) make_block(1, yp, sx);
+            if (grp == 4 && tid < 6 * 68) patch[tid] = pix;        // block 1 is built: the next patch's pixels
+            gload_a(grp == 4 ? 0 : grp + 2, ra);
+            C1_STAMP();
+            __syncthreads();
+            C1_STAMP();
+        }
+        if (more) swrite_a(ra);                            // group 0 of the next patch
+        epilogue(t);                                       // no LDS, no barrier: the next patch's interval 0 follows in the same interval
+        C1_STAMP();
+        if (!more) break;
+        slot = nslot;
+        t = xcd * per + slot;
+    }
+    zero_rings();
+#ifdef C1_PROBE
+    if (blockIdx.x == 8 && threadIdx.x == 0) {
+        probe[129] = __builtin_readcyclecounter();
+        probe[131] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // =====================================================================================================
@@ -675,6 +839,8 @@ static void launch_conv_pool(int gi, int kid, const float* packed, const float* 
 void launch_dense(const float* packed, const float* image, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     PadPlanes pp{{w.a2, w.b2, w.a3, w.b3, w.a4, w.b4}, {w.L2, w.L2, w.L3, w.L3, w.L4, w.L4}, {64, 64, 64, 128, 128, 128}, 192};
     const int pr = w.prec;
+    static const int c1slots = tuning_env("SPP_C1_SLOTS") ? atoi(tuning_env("SPP_C1_SLOTS")) : 64;
+    static const int c1delay = tuning_env("SPP_C1_DELAY") ? atoi(tuning_env("SPP_C1_DELAY")) : C1_PHASE_DELAY;
     static const int c1abl = tuning_env("SPP_C1_ABL") ? atoi(tuning_env("SPP_C1_ABL")) : 0;
     static const bool fuse1 = !(tuning_env("SPP_FUSE_CONV1") && atoi(tuning_env("SPP_FUSE_CONV1")) == 0);   // 0: separate conv1a / conv1b (A/B timing)
     if (pr == 4 && fuse1 && (w.L1.H & 1) == 0) {
@@ -687,11 +853,16 @@ void launch_dense(const float* packed, const float* image, const Workspace& w, h
                                       (int)C1_SMEM_BYTES);
             if (dev >= 0 && dev < 64) lds_ok[dev] = true;
         }
-        SPP_LAUNCH(hk, KID_CONV1A, s, zero_pad_rings_kernel, dim3(pp.nblocks), dim3(256), 0, s, pp);
         const int NT = w.L1.b * (w.L1.H / 2) * ((w.L1.W + 63) / 64);
-        SPP_LAUNCH(hk, KID_CONV1B, s, conv1ab_pool_f16_kernel, dim3(gatsspg::xcd_grid(1, NT)), dim3(512), C1_SMEM_BYTES, s, image,
+        const int per = (NT + 7) / 8;                            // patches per XCD band; 64 resident workgroups per XCD (2 per CU) walk it
+        SPP_LAUNCH(hk, KID_CONV1B, s, conv1ab_pool_f16_kernel, dim3(8 * std::min(per, c1slots)), dim3(512), C1_SMEM_BYTES, s, image,
                    packed + PW_C1A_W, packed + PW_C1A_B, reinterpret_cast<const unsigned short*>(packed + PW_TOTAL) + conv_wp_off(0),
-                   packed + conv_b_off(0), w.a2, w.L1, w.L2, c1abl);
+                   packed + conv_b_off(0), w.a2, w.L1, w.L2, pp, c1delay, c1abl
+#ifdef C1_PROBE
+                   ,
+                   (unsigned long long*)nullptr
+#endif
+        );
     } else {
         SPP_LAUNCH(hk, KID_CONV1A, s, conv1a_kernel, dim3((w.L1.ld + 255) / 256 + pp.nblocks, w.L1.b), dim3(256), 0, s, image,
                    packed + PW_C1A_W, packed + PW_C1A_B, w.a1, w.L1, pp);
