@@ -59,7 +59,7 @@ int check_launch(const char* what) {
 
 DescView padded_view(const Workspace& w) {
     DescView v;
-    v.p = w.dd; v.cstride = (size_t)w.L4.ldt; v.istride = (size_t)w.L4.ld; v.rstride = w.L4.Wp; v.origin = w.L4.Wp + 1;
+    v.p = w.dd; v.cstride = 1; v.istride = (size_t)w.L4.ld * DD; v.rstride = w.L4.Wp * DD; v.xstride = DD; v.origin = (w.L4.Wp + 1) * DD;   // convDb writes [position][256]
     return v;
 }
 
@@ -130,7 +130,7 @@ int spp_detect(const float* score_map, const float* dense_desc, int b, int H, in
     if (!score_map || !dense_desc || !keypoints || !scores || !descriptors || !counts) return fail("null argument");
     DescView v;
     const int Hc = H / 8, Wc = W / 8;   // floor: what three MaxPool2d(2, 2) leave
-    v.p = dense_desc; v.cstride = (size_t)Hc * Wc; v.istride = (size_t)DD * Hc * Wc; v.rstride = Wc; v.origin = 0;
+    v.p = dense_desc; v.cstride = (size_t)Hc * Wc; v.istride = (size_t)DD * Hc * Wc; v.rstride = Wc; v.xstride = 1; v.origin = 0;
     launch_detect(score_map, v, w, dp, keypoints, scores, descriptors, counts, nms_out, reinterpret_cast<hipStream_t>(stream),
                   nullptr);
     return check_launch("spp_detect");

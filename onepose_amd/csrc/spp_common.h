@@ -163,8 +163,10 @@ void launch_dense(const float* packed, const float* image, const Workspace& w, h
 void launch_export_dense(const Workspace& w, float* dense_desc, hipStream_t s);
 // spp_detect_kernels.hip
 void launch_score_map(const Workspace& w, float* score_map, hipStream_t s, ProfileHook* hk);
-// dense descriptors are read through (ptr, channel stride, image stride, row stride, origin offset)
-struct DescView { const float* p; size_t cstride, istride; int rstride, origin; };
+// dense descriptors are read through (ptr, channel stride, image stride, row stride, x stride, origin offset).  The extractor's own
+// plane is POSITION-major ([padded position][256 channels], cstride 1, xstride 256: a keypoint's 256 channels of one bilinear tap
+// are 1 KB contiguous); a caller's [b][256][Hc][Wc] tensor (spp_detect) is channel-major (xstride 1).
+struct DescView { const float* p; size_t cstride, istride; int rstride, xstride, origin; };
 void launch_detect(const float* score_map, DescView dv, const Workspace& w, const DetectParams& dp, float* keypoints,
                    float* scores, float* descriptors, int32_t* counts, float* nms_out, hipStream_t s, ProfileHook* hk);
 

@@ -124,7 +124,7 @@ template <class T, int CIN, int TAPS, bool PATCH, int PREC = 0>
 __global__ __launch_bounds__(T::THREADS) void conv_gemm_kernel(const float* __restrict__ Wt, const float* __restrict__ bias,
                                                                const unsigned short* __restrict__ Wp16, int rows,
                                                                const float* __restrict__ X, float* __restrict__ Y, FeatLayout L,
-                                                               int cout, int relu) {
+                                                               int cout, int relu, int tstride) {   // tstride > 0: Y is [column][tstride channels]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if constexpr (PREC == 4) gatsspg::fp16_saturate_mode();
     constexpr int CPS = CIN / BK;            // K slabs per tap
@@ -197,6 +197,24 @@ __global__ __launch_bounds__(T::THREADS) void conv_gemm_kernel(const float* __re
             int y, x;
             ok = feat_valid(L, col % L.ld, y, x);
             store = true;
+        }
+        if (tstride > 0) {
+            // position-major output (the dense descriptors): a lane's registers 4 g .. 4 g + 3 are four consecutive channels
+            // of its column -> one 16-byte store each (cout is a multiple of 4 rows wherever this is used)
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row0 = rt * T::BM + (wm * T::TM + tm) * 32 + 8 * g + 4 * half;
+                    if (row0 < cout && store) {
+                        const float4 bs = *reinterpret_cast<const float4*>(bias + row0);
+                        float4 v = {acc[tm][tn][4 * g] + bs.x, acc[tm][tn][4 * g + 1] + bs.y, acc[tm][tn][4 * g + 2] + bs.z, acc[tm][tn][4 * g + 3] + bs.w};
+                        if (relu) v = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+                        if (!ok) v = {0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<float4*>(Y + (size_t)col * tstride + row0) = v;
+                    }
+                }
+            continue;
         }
 #pragma unroll
         for (int tm = 0; tm < T::TM; ++tm)
@@ -660,13 +678,24 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ X, 
     Y[(size_t)c * Lo.ldt + (size_t)im * Lo.ld + q] = v;
 }
 
-// dense descriptors out of the padded plane: [b][256][Hc][Wc]
+// dense descriptors out of the padded position-major plane ([position][256]): [b][256][Hc][Wc].  A workgroup transposes
+// 64 cells x 64 channels through LDS (reads: 256 B per cell, writes: 256 B per channel).
 __global__ __launch_bounds__(256) void export_dense_kernel(const float* __restrict__ X, FeatLayout L, float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int c = blockIdx.y, im = blockIdx.z;
-    if (i >= L.H * L.W) return;
-    const int y = i / L.W, x = i - y * L.W;
-    out[((size_t)im * DD + c) * L.H * L.W + i] = X[(size_t)c * L.ldt + (size_t)im * L.ld + (size_t)(y + 1) * L.Wp + x + 1];
+    __shared__ float tile[64][65];
+    const int i0 = blockIdx.x * 64, c0 = blockIdx.y * 64, im = blockIdx.z;
+    const int HW = L.H * L.W;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int ci = e >> 6, ch = e & 63, i = i0 + ci;
+        if (i < HW) {
+            const int y = i / L.W, x = i - y * L.W;
+            tile[ci][ch] = X[((size_t)im * L.ld + (size_t)(y + 1) * L.Wp + x + 1) * DD + c0 + ch];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int ch = e >> 6, ci = e & 63, i = i0 + ci;
+        if (i < HW) out[((size_t)im * DD + c0 + ch) * HW + i] = tile[ci][ch];
+    }
 }
 
 // =====================================================================================================
@@ -758,14 +787,16 @@ static void launch_conv_t(int gi, int kid, const float* packed, const float* X, 
             auto kern = conv_gemm_kernel<T, CIN, TAPS, true, PREC>;
             const int NT = L.b * ((L.H + 1) / 2) * ((L.W + T::BN / 2 - 1) / (T::BN / 2));
             SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(MT, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>()), s,
-                       packed + conv_w_off(gi), packed + conv_b_off(gi), planes, kConv[gi].rows, X, Y, L, cout, relu);
+                       packed + conv_w_off(gi), packed + conv_b_off(gi), planes, kConv[gi].rows, X, Y, L, cout, relu, 0);
             return;
         }
     }
     auto kern = conv_gemm_kernel<T, CIN, TAPS, false, PREC>;
     const int NT = L.ldt / T::BN;
+    static_assert(conv_b_off(NGEMM - 1) % 4 == 0, "the position-major epilogue reads the bias as float4");
+    const int tstride = gi == NGEMM - 1 ? DD : 0;      // convDb: the dense descriptors are kept position-major (DescView, spp_common.h)
     SPP_LAUNCH(hk, kid, s, kern, dim3(gatsspg::xcd_grid(MT, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>()), s, packed + conv_w_off(gi),
-               packed + conv_b_off(gi), planes, kConv[gi].rows, X, Y, L, cout, relu);
+               packed + conv_b_off(gi), planes, kConv[gi].rows, X, Y, L, cout, relu, tstride);
 }
 
 // Tile shape per GEMM convolution: 0 = 64x128, 1 = 64x64, 2 = 128x64 (rows x columns), 3 = 64x128 on 8 waves,
@@ -880,7 +911,7 @@ void launch_dense(const float* packed, const float* image, const Workspace& w, h
 }
 
 void launch_export_dense(const Workspace& w, float* dense_desc, hipStream_t s) {
-    hipLaunchKernelGGL(export_dense_kernel, dim3((w.L4.H * w.L4.W + 255) / 256, DD, w.L4.b), dim3(256), 0, s, w.dd, w.L4,
+    hipLaunchKernelGGL(export_dense_kernel, dim3((w.L4.H * w.L4.W + 63) / 64, DD / 64, w.L4.b), dim3(256), 0, s, w.dd, w.L4,
                        dense_desc);
 }
 

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void cellnorm_kernel(DescView dv, int Hc, int 
     float ss = 0.f;
     if (cell < Hc * Wc) {
         const int cy = cell / Wc, cx = cell - cy * Wc;
-        const float* p = dv.p + (size_t)im * dv.istride + dv.origin + (size_t)cy * dv.rstride + cx + (size_t)(grp * 64) * dv.cstride;
+        const float* p = dv.p + (size_t)im * dv.istride + dv.origin + (size_t)cy * dv.rstride + (size_t)cx * dv.xstride + (size_t)(grp * 64) * dv.cstride;
 #pragma unroll 8
         for (int c = 0; c < 64; ++c) {
             const float v = p[(size_t)c * dv.cstride];
@@ -418,6 +418,18 @@ __global__ __launch_bounds__(256) void cellnorm_kernel(DescView dv, int Hc, int 
         const float tot = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
         invn[(size_t)im * Hc * Wc + cell] = 1.f / fmaxf(sqrtf(tot), 1e-12f);
     }
+}
+
+// position-major descriptors (cstride 1): one wave per cell, a lane owns 4 consecutive channels (one 16-byte load), 4 cells per workgroup
+__global__ __launch_bounds__(256) void cellnorm_pm_kernel(DescView dv, int Hc, int Wc, float* __restrict__ invn) {
+    const int lane = threadIdx.x & 63, cell = blockIdx.x * 4 + (threadIdx.x >> 6), im = blockIdx.y;
+    if (cell >= Hc * Wc) return;
+    const int cy = cell / Wc, cx = cell - cy * Wc;
+    const float4 v = *reinterpret_cast<const float4*>(dv.p + (size_t)im * dv.istride + dv.origin + (size_t)cy * dv.rstride + (size_t)cx * dv.xstride + 4 * lane);
+    float ss = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (lane == 0) invn[(size_t)im * Hc * Wc + cell] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
 }
 
 // one workgroup = 16 keypoints x 256 channels (16 channel groups of 16)
@@ -459,29 +471,53 @@ __global__ __launch_bounds__(256) void sample_kernel(DescView dv, int Hc, int Wc
         const float w = (1.f - fabsf(ix - (float)xi)) * (1.f - fabsf(iy - (float)yi));
         const int cell = ok ? yi * Wc + xi : 0;
         wq[q] = ok ? w * invn[(size_t)im * Hc * Wc + cell] : 0.f;
-        off[q] = ok ? yi * dv.rstride + xi : 0;
+        off[q] = ok ? yi * dv.rstride + xi * dv.xstride : 0;
     }
     const float* base = dv.p + (size_t)im * dv.istride + dv.origin;
     float v[16];
     float ss = 0.f;
     // 8 channels x 4 taps = 32 gathers requested before any is used (written as one fmaf chain per channel hipcc waited for
     // every gather -- s_waitcnt vmcnt(0) -- before issuing the next: 64 dependent L2 round trips per thread)
+    if (dv.cstride == 1) {
+        // position-major plane (the extractor's own): this thread's 16 channels of a tap are 64 contiguous bytes -- 16 float4
+        // loads instead of 64 scattered dwords (the channel-major gathers touch 1024 cache lines per keypoint, this form 16)
+        float4 u[4][4];
 #pragma unroll
-    for (int k0 = 0; k0 < 16; k0 += 8) {
-        float t[8][4];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float* pc = base + (size_t)(grp * 16 + k0 + k) * dv.cstride;
+            for (int j = 0; j < 4; ++j) u[q][j] = *reinterpret_cast<const float4*>(base + off[q] + grp * 16 + 4 * j);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) t[k][q] = pc[off[q]];
+        for (int j = 0; j < 4; ++j) {
+            const float tq[4][4] = {{u[0][j].x, u[1][j].x, u[2][j].x, u[3][j].x}, {u[0][j].y, u[1][j].y, u[2][j].y, u[3][j].y},
+                                    {u[0][j].z, u[1][j].z, u[2][j].z, u[3][j].z}, {u[0][j].w, u[1][j].w, u[2][j].w, u[3][j].w}};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a = fmaf(tq[c][q], wq[q], a);
+                v[4 * j + c] = a;
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float a = 0.f;
+        for (int k = 0; k < 16; ++k) ss = fmaf(v[k], v[k], ss);
+    } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a = fmaf(t[k][q], wq[q], a);
-            v[k0 + k] = a;
-            ss = fmaf(a, a, ss);
+        for (int k0 = 0; k0 < 16; k0 += 8) {
+            float t[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* pc = base + (size_t)(grp * 16 + k0 + k) * dv.cstride;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[k][q] = pc[off[q]];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float a = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a = fmaf(t[k][q], wq[q], a);
+                v[k0 + k] = a;
+                ss = fmaf(a, a, ss);
+            }
         }
     }
     part[grp][kl] = ss;
@@ -553,7 +589,10 @@ void launch_detect(const float* score_map, DescView dv, const Workspace& w, cons
     }
     SPP_LAUNCH(hk, KID_SCATTER, s, scatter_kernel, dim3(16, b), dim3(256), 0, s, H * W, w.ncand, w.cand, w.surv, w.rank,
                dp.max_keypoints, dp.capacity, w.sel, counts);
-    SPP_LAUNCH(hk, KID_CELLNORM, s, cellnorm_kernel, dim3((Hc * Wc + 63) / 64, b), dim3(256), 0, s, dv, Hc, Wc, w.invn);
+    if (dv.cstride == 1 && dv.xstride % 4 == 0)
+        SPP_LAUNCH(hk, KID_CELLNORM, s, cellnorm_pm_kernel, dim3((Hc * Wc + 3) / 4, b), dim3(256), 0, s, dv, Hc, Wc, w.invn);
+    else
+        SPP_LAUNCH(hk, KID_CELLNORM, s, cellnorm_kernel, dim3((Hc * Wc + 63) / 64, b), dim3(256), 0, s, dv, Hc, Wc, w.invn);
     SPP_LAUNCH(hk, KID_SAMPLE, s, sample_kernel, dim3((dp.capacity + 15) / 16, b), dim3(256), 0, s, dv, Hc, Wc, w.invn, nms,
                w.sel, counts, H, W, dp.align_corners, dp.capacity, keypoints, scores, descriptors);
 }
