@@ -328,8 +328,8 @@ __global__ __launch_bounds__(T::THREADS) void conv_pool_kernel(const float* __re
 // put the two residents of a CU out of phase (`phase_delay`, no gain at any value: kept as a tuning knob at 0); ONE 1024-thread
 // workgroup whose halves run one barrier interval apart (89 us: every long staging interval stalls the other half at the shared
 // barrier); conv1a on the vector ALU (432 FMAs per thread and patch: as many VALU cycles as the MFMAs take, 82 us).
-// The epilogue needs no LDS and no barrier: a wave's 32 columns are 16 pixels of BOTH patch rows, so the 2x2 maximum is a
-// quad-permute (pixel pairs are neighbouring lanes) and a 16-lane swizzle (the rows), and the pooled values go to HBM from registers.
+// The epilogue needs no LDS and no barrier: a wave's 32 columns are 16 pixels of BOTH patch rows, so the 2x2 maximum is two lane
+// swizzles (the pixel pair: lane ^ 4, the rows: lane ^ 16), and the pooled values go to HBM from registers.
 // =====================================================================================================
 constexpr int C1_PHASE_DELAY = 0;                     // x 64 cycles of start delay for the second wave of workgroups (measured: no gain)
 constexpr int C1_BW = 66, C1_COLS = 4 * C1_BW;        // resident block: 4 rows x 66 positions
@@ -507,8 +507,14 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
     };
 
     const int arow = (wm * 32 + l31) * C1_KS;
-    // a wave's 32 columns: pixels 16 wn .. 16 wn + 15 of patch row l31 / 16 (the 2x2 pooling window stays inside the wave)
-    const int jbase = ((l31 >> 4) + 1) * C1_BW + 16 * wn + (l31 & 15) + 1;   // the column's position in the block for the centre tap
+    // a wave's 32 columns: pixels 16 wn .. 16 wn + 15 of patch row l31 / 16 (the 2x2 pooling window stays inside the wave).  Lanes
+    // 4-11 of a 16-lane row take the EVEN pixels, lanes 0-3 and 12-15 the odd ones: a 16-byte LDS read is served in the lane groups
+    // {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31}, i.e. eight lanes of patch row 0 and eight of row 1, 66 = 2 (mod 16) positions
+    // apart; with odd pixels in one row and even ones in the other the sixteen 80-byte rows of a group sit on sixteen different bank
+    // quads (pixels in lane order: two groups of eight collide on two of them -- 8.4 M conflict cycles of 23 M LDS cycles, PMC)
+    const int m16 = l31 & 15;
+    const int px16 = (m16 >= 4 && m16 < 12) ? 2 * (m16 - 4) : (m16 < 4 ? 2 * m16 + 1 : 2 * (m16 - 12) + 9);
+    const int jbase = ((l31 >> 4) + 1) * C1_BW + 16 * wn + px16 + 1;         // the column's position in the block for the centre tap
     f32x16 acc;
     // fragment sets (one 16-deep k step of a tap: A hi / lo, B hi / lo) are requested one to two steps ahead of the four MFMAs that
     // consume them (two sets: a third one spills -- and a scratch reload on the way into the epilogue costs a memory round trip)
@@ -556,10 +562,10 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
         }
         const int im = t / (HP * SEG), r0 = t - im * (HP * SEG);
         const int yp = r0 / SEG, sx = r0 - yp * SEG;
-        int px2 = 8 * wn + ((l31 & 15) >> 1);              // pooled pixel of this lane's pair within the 32-pixel pooled segment
+        int px2 = 8 * wn + ((l31 & 15) - 4);               // pooled pixel of an even-pixel lane (4-11) within the 32-pixel pooled segment
         asm volatile("" : "+v"(px2));                      // (addresses recomputed here, not kept alive across the K loop)
         float* dst = Y2 + (size_t)im * L2.ld + (size_t)(yp + 1) * L2.Wp + 1 + 32 * sx + px2;
-        const bool writer = (l31 & 17) == 0 && 32 * sx + px2 < L.W / 2;
+        const bool writer = l31 >= 4 && l31 < 12 && 32 * sx + px2 < L.W / 2;
         float hmax[16];
         int other[16];
 #pragma unroll
@@ -569,11 +575,16 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float v = fmaxf(acc[4 * g + q] + bb[q], 0.f);
-                hmax[4 * g + q] = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+                hmax[4 * g + q] = v;
             }
         }
+        // pixel 2 j sits in lane 4 + j, pixel 2 j + 1 in lane j (j < 4) or 8 + j: lane ^ 4; the other patch row: lane ^ 16
 #pragma unroll
-        for (int r = 0; r < 16; ++r) other[r] = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, hmax[r]), 0x401F);   // lane ^ 16, all 16 in flight
+        for (int r = 0; r < 16; ++r) other[r] = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, hmax[r]), 0x101F);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hmax[r] = fmaxf(hmax[r], __builtin_bit_cast(float, other[r]));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) other[r] = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, hmax[r]), 0x401F);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             int row0 = wm * 32 + 8 * g + 4 * half;
