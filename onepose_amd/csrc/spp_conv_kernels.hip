@@ -337,17 +337,22 @@ constexpr int C1_KS = 40;                             // 16-bit elements per LDS
 constexpr int C1_A_PLANE = 64 * C1_KS, C1_A_STAGE = 2 * C1_A_PLANE;   // hi + lo planes of one tap's 64 x 32 weight slab
 constexpr int C1_B_PLANE = C1_COLS * C1_KS;
 constexpr int C1_HALF_U16 = 3 * C1_A_STAGE + 2 * C1_B_PLANE + 2 * 6 * 68;   // A buffer (3 taps), block hi / lo, fp32 pixel patch
-constexpr int C1_SHARED_BYTES = 2 * 2 * 64 * 16 + 64 * 4;                   // conv1a's A fragments [2 slabs][hi | lo][64 lanes], conv1b's bias
+constexpr int C1_SHARED_BYTES = 2 * 2 * 64 * 16 + 128 * 4;                  // conv1a's A fragments [2 slabs][hi | lo][64 lanes], conv1b's bias
 constexpr size_t C1_SMEM_BYTES = 2 * (size_t)C1_HALF_U16 + C1_SHARED_BYTES;
 static_assert(2 * C1_SMEM_BYTES <= 160 * 1024 && (2 * C1_HALF_U16) % 16 == 0, "two workgroups per CU");
 
+// C1A: the first layer (input = the image, conv1a recomputed into the resident block); otherwise the block is LOADED from the
+// 64-channel padded plane X of the same resolution (its zero pad ring is the halo) and split once -- conv2a, conv2b, conv3a: the
+// generic loop splits every activation once per tap and row tile (9 - 18 times).  POOL: 2x2 maximum into the half-resolution plane
+// (layout LY), otherwise bias + ReLU into the full-resolution plane.  rows = output channels (64 per workgroup item, rows / 64 items per patch).
+template <bool C1A, bool POOL>
 __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* __restrict__ img, const float* __restrict__ w1a,
-                                                                const float* __restrict__ b1a, const unsigned short* __restrict__ Wp16,
-                                                                const float* __restrict__ bias, float* __restrict__ Y2, FeatLayout L,
-                                                                FeatLayout L2, PadPlanes pp, int phase_delay, int abl   // abl: timing ablations (tuning builds), 0 in the product
+                                                               const float* __restrict__ b1a, const unsigned short* __restrict__ Wp16,
+                                                               const float* __restrict__ bias, float* __restrict__ Y2, FeatLayout L,
+                                                               FeatLayout L2, int rows, PadPlanes pp, int phase_delay, int abl   // abl: timing ablations (tuning builds), 0 in the product
 #ifdef C1_PROBE
-                                                                ,
-                                                                unsigned long long* __restrict__ probe   // tools/conv1ab_probe.hip
+                                                               ,
+                                                               unsigned long long* __restrict__ probe   // tools/conv1ab_probe.hip
 #endif
 ) {
 #ifdef C1_PROBE
@@ -380,7 +385,8 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
     float* const bias_s = reinterpret_cast<float*>(wfrag + 2 * 2 * 64);
 
     const int SEG = (L.W + 63) / 64, HP = L.H / 2;
-    const int NT = L.b * HP * SEG;
+    const int MT = rows >> 6;                          // 64-channel row tiles: items (patch, row tile), the row tiles of a patch back to back
+    const int NT = L.b * HP * SEG * MT;
     const int per = (NT + 7) / 8;                      // XCD bands of consecutive patches (see conv_gemm_kernel)
     const int nslots = gridDim.x >> 3;                 // workgroups per XCD; each walks its band with that stride
     const int xcd = blockIdx.x & 7;
@@ -392,13 +398,14 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
     constexpr int K1B = 9 * 64;
     const int a_plane = __builtin_amdgcn_readfirstlane(tid >> 8);          // waves 0-3: hi plane, 4-7: lo plane
     const int a_r = (tid & 255) >> 2, a_c8 = tid & 3;
-    const unsigned short* a_src = Wp16 + (size_t)a_plane * 64 * K1B + (size_t)a_r * 32 + a_c8 * 8;
+    const unsigned short* a_src = Wp16 + (size_t)a_plane * rows * K1B + (size_t)a_r * 32 + a_c8 * 8;
     const int a_soff = a_plane * C1_A_PLANE + a_r * C1_KS + a_c8 * 8;
-    // group grp = cc * 3 + (dy + 1): the three taps dx = -1, 0, 1 of one stencil row
-    auto gload_a = [&](int grp, u32x4 (&ra)[3]) {
+    // group grp = cc * 3 + (dy + 1): the three taps dx = -1, 0, 1 of one stencil row; rt = row tile of the item
+    auto gload_a = [&](int grp, int rt, u32x4 (&ra)[3]) {
         const int cc = grp / 3, dyi = grp - cc * 3;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) ra[d] = *reinterpret_cast<const u32x4*>(a_src + (size_t)(((dyi * 3 + d) * 2 + cc) * 64) * 32);
+        for (int d = 0; d < 3; ++d)
+            ra[d] = *reinterpret_cast<const u32x4*>(a_src + ((size_t)((dyi * 3 + d) * 2 + cc) * rows + rt * 64) * 32);
     };
     auto swrite_a = [&](const u32x4 (&ra)[3]) {
 #pragma unroll
@@ -493,9 +500,35 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
             }
         }
     };
+    // the loaded form: position j of the block is X[ch][im][(2 yp + r) * Wp + 64 sx + x] (padded coordinates: the plane's zero ring is
+    // the halo); a lane owns 16 channels of its position: 16 loads (each coalesced over the wave's positions), 8 splits, 2 + 2 16-byte stores
+    auto load_tile = [&](int tt, int cc, int im, int yp, int sx) {
+        int j = 32 * tt + l31;
+        asm volatile("" : "+v"(j));
+        if (j >= C1_COLS) return;
+        const int r = j / C1_BW, x = j - r * C1_BW;
+        const float* src = img + (size_t)im * L.ld + (size_t)(2 * yp + r) * L.Wp + 64 * sx + x + (size_t)(cc * 32 + 16 * half) * L.ldt;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = src[(size_t)i * L.ldt];
+        unsigned hi[8], lo[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gatsspg::fp16_split2(v[2 * i], v[2 * i + 1], hi[i], lo[i]);
+        const int o = j * C1_KS + 16 * half;
+        *reinterpret_cast<u32x4*>(Bhi + o) = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(Bhi + o + 8) = (u32x4){hi[4], hi[5], hi[6], hi[7]};
+        *reinterpret_cast<u32x4*>(Blo + o) = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+        *reinterpret_cast<u32x4*>(Blo + o + 8) = (u32x4){lo[4], lo[5], lo[6], lo[7]};
+    };
     // 264 positions = 8 tiles of 32 + 8: wave w builds tile w, wave 0 also the tail
-    auto make_block = [&](int cc, int yp, int sx) {
+    auto make_block = [&](int cc, int im, int yp, int sx) {
         C1_STAMP();
+        if constexpr (!C1A) {
+            load_tile(wave, cc, im, yp, sx);
+            if (wave == 7) load_tile(8, cc, im, yp, sx);
+            C1_STAMP();
+            return;
+        }
         if (wave == 0) {
             const int tts[2] = {0, 8};
             block_tiles(std::integral_constant<int, 2>{}, tts, cc, yp, sx);
@@ -555,13 +588,33 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
     };
 
     // ---- epilogue of a finished patch, from registers: bias + ReLU, 2x2 max (pixel pairs = neighbouring lanes, rows = lanes 16 apart)
-    auto epilogue = [&](int t) {
+    auto epilogue = [&](int item) {
         if (abl & 8) {
             if (acc[0] == 12345.f) Y2[0] = acc[1];
             return;
         }
+        const int t = item / MT, rt = item - t * MT;
         const int im = t / (HP * SEG), r0 = t - im * (HP * SEG);
         const int yp = r0 / SEG, sx = r0 - yp * SEG;
+        if constexpr (!POOL) {
+            // bias + ReLU into the full-resolution plane: lane -> (patch row l31 / 16, pixel 16 wn + px16), a register per channel
+            int col = (2 * yp + (l31 >> 4) + 1) * L2.Wp + 64 * sx + 16 * wn + px16 + 1;
+            asm volatile("" : "+v"(col));
+            const bool inimg = 64 * sx + 16 * wn + px16 < L.W;
+            float* dstc = Y2 + (size_t)im * L2.ld + col;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int row0 = rt * 64 + wm * 32 + 8 * g + 4 * half;
+                asm volatile("" : "+v"(row0));
+                const float4 bs = *reinterpret_cast<const float4*>(bias_s + row0);
+                const float bb[4] = {bs.x, bs.y, bs.z, bs.w};
+                float* drow = dstc + (size_t)row0 * L2.ldt;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (inimg) drow[(size_t)q * L2.ldt] = fmaxf(acc[4 * g + q] + bb[q], 0.f);
+            }
+            return;
+        }
         int px2 = 8 * wn + ((l31 & 15) - 4);               // pooled pixel of an even-pixel lane (4-11) within the 32-pixel pooled segment
         asm volatile("" : "+v"(px2));                      // (addresses recomputed here, not kept alive across the K loop)
         float* dst = Y2 + (size_t)im * L2.ld + (size_t)(yp + 1) * L2.Wp + 1 + 32 * sx + px2;
@@ -570,7 +623,7 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
         int other[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 bs = *reinterpret_cast<const float4*>(bias_s + wm * 32 + 8 * g + 4 * half);   // rows mfma_row(4 g .. 4 g + 3, half)
+            const float4 bs = *reinterpret_cast<const float4*>(bias_s + rt * 64 + wm * 32 + 8 * g + 4 * half);   // rows mfma_row(4 g .. 4 g + 3, half)
             const float bb[4] = {bs.x, bs.y, bs.z, bs.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -587,7 +640,7 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
         for (int r = 0; r < 16; ++r) other[r] = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, hmax[r]), 0x401F);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            int row0 = wm * 32 + 8 * g + 4 * half;
+            int row0 = rt * 64 + wm * 32 + 8 * g + 4 * half;
             asm volatile("" : "+v"(row0));
             float* drow = dst + (size_t)row0 * L2.ldt;
 #pragma unroll
@@ -600,8 +653,10 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
     // read here, and this kernel's own output plane gets pixels only.  Done after the patches (at the start it delays every
     // workgroup's first patch: +4.6 us measured, against 5.8 us for a launch of its own).
     auto zero_rings = [&]() {
+        if constexpr (C1A) {
 #pragma unroll
-        for (int i = 0; i < PadPlanes::N; ++i) zero_pad_ring(pp.p[i], pp.L[i], pp.C[i], blockIdx.x * 512 + threadIdx.x, gridDim.x * 512);
+            for (int i = 0; i < PadPlanes::N; ++i) zero_pad_ring(pp.p[i], pp.L[i], pp.C[i], blockIdx.x * 512 + threadIdx.x, gridDim.x * 512);
+        }
     };
     int slot = blockIdx.x >> 3;
     if (slot >= per || xcd * per + slot >= NT) {
@@ -609,16 +664,18 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
         return;
     }
     u32x4 ra[3];
-    gload_a(0, ra);
-    int t = xcd * per + slot;
-    if (tid < 6 * 68) patch[tid] = gload_patch(t, true);
-    if (wave < 2) {                                        // conv1a's A fragments of both channel slabs
-        u32x4 whi, wlo;
-        load_w1a(wave, whi, wlo);
-        wfrag[(wave * 2 + 0) * 64 + lane] = whi;
-        wfrag[(wave * 2 + 1) * 64 + lane] = wlo;
+    int item = xcd * per + slot;                           // (patch, row tile)
+    gload_a(0, item % MT, ra);
+    if constexpr (C1A) {
+        if (tid < 6 * 68) patch[tid] = gload_patch(item, true);
+        if (wave < 2) {                                    // conv1a's A fragments of both channel slabs
+            u32x4 whi, wlo;
+            load_w1a(wave, whi, wlo);
+            wfrag[(wave * 2 + 0) * 64 + lane] = whi;
+            wfrag[(wave * 2 + 1) * 64 + lane] = wlo;
+        }
     }
-    if (wave == 2) bias_s[lane] = bias[lane];
+    if (wave >= 2 && wave < 2 + (rows >> 6)) bias_s[(wave - 2) * 64 + lane] = bias[(wave - 2) * 64 + lane];
     if (2 * slot >= nslots)                                // the workgroups that land beside the first wave of the grid (tuning knob, 0)
         for (int i = 0; i < phase_delay; ++i) __builtin_amdgcn_s_sleep(1);
     swrite_a(ra);                                          // group 0
@@ -626,21 +683,24 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
     // The A slab registers are written to the buffer FIRST in every staging interval and re-requested LAST, so that they are not
     // live across the block builds and the epilogue (the kernel sits at the 128-register limit of 4 waves per SIMD).
     for (;;) {
+        const int t = item / MT, rt = item - t * MT;
         const int im = t / (HP * SEG), r0 = t - im * (HP * SEG);
         const int yp = r0 / SEG, sx = r0 - yp * SEG;       // pooled row, 64-pixel segment
         const int nslot = slot + nslots;
         const bool more = nslot < per && xcd * per + nslot < NT;
-        const float pix = gload_patch(xcd * per + nslot, more);   // the next patch's pixel: in flight until the staging interval after group 4
+        const int nitem = xcd * per + nslot;
+        float pix = 0.f;
+        if constexpr (C1A) pix = gload_patch(nitem, more); // the next patch's pixel: in flight until the staging interval after group 4
         // interval 0: resident block of channel slab 0 (the A slabs of group 0 are in the buffer)
-        if (!(abl & 1)) make_block(0, yp, sx);
-        gload_a(1, ra);
+        if (!(abl & 1)) make_block(0, im, yp, sx);
+        gload_a(1, rt, ra);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         C1_STAMP();
         __syncthreads();
         C1_STAMP();
         // intervals 1..11: group grp = 3 taps x 8 MFMAs from the A buffer | the next group's slabs (in registers since the previous
-        // staging interval) are written, the one after is requested (after group 5 comes group 0 of the next patch)
+        // staging interval) are written, the one after is requested (after group 5 comes group 0 of the next item)
         for (int grp = 0; grp < 6; ++grp) {
             if (!(abl & 2)) compute3(grp % 3);
             C1_STAMP();
@@ -649,19 +709,22 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
             if (grp == 5) break;
             swrite_a(ra);
             asm volatile("" ::: "memory");
-            if (grp == 2 && !(abl & 1)) make_block(1, yp, sx);
-            if (grp == 4 && tid < 6 * 68) patch[tid] = pix;        // block 1 is built: the next patch's pixels
-            gload_a(grp == 4 ? 0 : grp + 2, ra);
+            if (grp == 2 && !(abl & 1)) make_block(1, im, yp, sx);
+            if constexpr (C1A) {
+                if (grp == 4 && tid < 6 * 68) patch[tid] = pix;    // block 1 is built: the next patch's pixels
+            }
+            if (grp == 4) gload_a(0, more ? nitem % MT : 0, ra);
+            else gload_a(grp + 2, rt, ra);
             C1_STAMP();
             __syncthreads();
             C1_STAMP();
         }
-        if (more) swrite_a(ra);                            // group 0 of the next patch
-        epilogue(t);                                       // no LDS, no barrier: the next patch's interval 0 follows in the same interval
+        if (more) swrite_a(ra);                            // group 0 of the next item
+        epilogue(item);                                    // no LDS, no barrier: the next item's interval 0 follows in the same interval
         C1_STAMP();
         if (!more) break;
         slot = nslot;
-        t = xcd * per + slot;
+        item = nitem;
     }
     zero_rings();
 #ifdef C1_PROBE
@@ -885,34 +948,49 @@ void launch_dense(const float* packed, const float* image, const Workspace& w, h
     static const int c1delay = tuning_env("SPP_C1_DELAY") ? atoi(tuning_env("SPP_C1_DELAY")) : C1_PHASE_DELAY;
     static const int c1abl = tuning_env("SPP_C1_ABL") ? atoi(tuning_env("SPP_C1_ABL")) : 0;
     static const bool fuse1 = !(tuning_env("SPP_FUSE_CONV1") && atoi(tuning_env("SPP_FUSE_CONV1")) == 0);   // 0: separate conv1a / conv1b (A/B timing)
-    if (pr == 4 && fuse1 && (w.L1.H & 1) == 0) {
-        // split-fp16: conv1a is recomputed inside conv1b's workgroups (its 64-channel full-resolution plane never exists)
-        static bool lds_ok[64] = {};
+    static const bool resident = !(tuning_env("SPP_RESIDENT") && atoi(tuning_env("SPP_RESIDENT")) == 0);   // 0: generic loop for conv2a / conv2b / conv3a
+    // the resident-block kernel (split-fp16 only): gi = GEMM convolution, X = input (the image for the first layer), Y = output plane
+    auto resident_conv = [&](auto c1a, auto pool, int gi, int kid, const float* X, float* Y, const FeatLayout& L, const FeatLayout& LY) {
+        auto kern = conv1ab_pool_f16_kernel<decltype(c1a)::value, decltype(pool)::value>;
+        static bool lds_ok[64] = {};                   // per instantiation of this lambda
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !lds_ok[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1ab_pool_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)C1_SMEM_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C1_SMEM_BYTES);
             if (dev >= 0 && dev < 64) lds_ok[dev] = true;
         }
-        const int NT = w.L1.b * (w.L1.H / 2) * ((w.L1.W + 63) / 64);
-        const int per = (NT + 7) / 8;                            // patches per XCD band; 64 resident workgroups per XCD (2 per CU) walk it
-        SPP_LAUNCH(hk, KID_CONV1B, s, conv1ab_pool_f16_kernel, dim3(8 * std::min(per, c1slots)), dim3(512), C1_SMEM_BYTES, s, image,
-                   packed + PW_C1A_W, packed + PW_C1A_B, reinterpret_cast<const unsigned short*>(packed + PW_TOTAL) + conv_wp_off(0),
-                   packed + conv_b_off(0), w.a2, w.L1, w.L2, pp, c1delay, c1abl
+        const int rows = kConv[gi].rows;
+        const int NT = L.b * (L.H / 2) * ((L.W + 63) / 64) * (rows / 64);
+        const int per = (NT + 7) / 8;                  // items per XCD band; 64 resident workgroups per XCD (2 per CU) walk it
+        SPP_LAUNCH(hk, kid, s, kern, dim3(8 * std::min(per, c1slots)), dim3(512), C1_SMEM_BYTES, s, X, packed + PW_C1A_W, packed + PW_C1A_B,
+                   reinterpret_cast<const unsigned short*>(packed + PW_TOTAL) + conv_wp_off(gi), packed + conv_b_off(gi), Y, L, LY, rows, pp,
+                   c1delay, c1abl
 #ifdef C1_PROBE
                    ,
                    (unsigned long long*)nullptr
 #endif
         );
+    };
+    using std::true_type;
+    using std::false_type;
+    auto fits = [](const FeatLayout& L) { return (L.H & 1) == 0 && L.W % 64 == 0; };
+    if (pr == 4 && fuse1 && (w.L1.H & 1) == 0) {
+        // split-fp16: conv1a is recomputed inside conv1b's workgroups (its 64-channel full-resolution plane never exists)
+        resident_conv(true_type{}, true_type{}, 0, KID_CONV1B, image, w.a2, w.L1, w.L2);
     } else {
         SPP_LAUNCH(hk, KID_CONV1A, s, conv1a_kernel, dim3((w.L1.ld + 255) / 256 + pp.nblocks, w.L1.b), dim3(256), 0, s, image,
                    packed + PW_C1A_W, packed + PW_C1A_B, w.a1, w.L1, pp);
         launch_conv_pool<64>(0, KID_CONV1B, packed, w.a1, w.b1, w.a2, w.L1, w.L2, s, hk, pr);     // conv1b + pool
     }
-    launch_conv<64, 9>(1, KID_CONV2, packed, w.a2, w.b2, w.L2, 1, s, hk, pr);
-    launch_conv_pool<64>(2, KID_CONV2, packed, w.b2, w.a2, w.a3, w.L2, w.L3, s, hk, pr);      // conv2b + pool (a2 is free: scratch)
-    launch_conv<64, 9>(3, KID_CONV3A, packed, w.a3, w.b3, w.L3, 1, s, hk, pr);
+    if (pr == 4 && resident && fits(w.L2)) {
+        resident_conv(false_type{}, false_type{}, 1, KID_CONV2, w.a2, w.b2, w.L2, w.L2);           // conv2a
+        resident_conv(false_type{}, true_type{}, 2, KID_CONV2, w.b2, w.a3, w.L2, w.L3);            // conv2b + pool
+    } else {
+        launch_conv<64, 9>(1, KID_CONV2, packed, w.a2, w.b2, w.L2, 1, s, hk, pr);
+        launch_conv_pool<64>(2, KID_CONV2, packed, w.b2, w.a2, w.a3, w.L2, w.L3, s, hk, pr);      // conv2b + pool (a2 is free: scratch)
+    }
+    if (pr == 4 && resident && fits(w.L3)) resident_conv(false_type{}, false_type{}, 3, KID_CONV3A, w.a3, w.b3, w.L3, w.L3);   // conv3a
+    else launch_conv<64, 9>(3, KID_CONV3A, packed, w.a3, w.b3, w.L3, 1, s, hk, pr);
     launch_conv_pool<128>(4, KID_CONV3B, packed, w.b3, w.c3, w.a4, w.L3, w.L4, s, hk, pr);    // conv3b + pool
     launch_conv<128, 9>(5, KID_CONV4, packed, w.a4, w.b4, w.L4, 1, s, hk, pr);
     launch_conv<128, 9>(6, KID_CONV4, packed, w.b4, w.a4, w.L4, 1, s, hk, pr);

@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dimg, img.data(), img.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w1a.data(), w1a.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, b1a.data(), 256, hipMemcpyHostToDevice)); CK(hipMemcpy(dbias, bias.data(), 256, hipMemcpyHostToDevice));
     CK(hipMemcpy(dwp, wp.data(), wp.size() * 2, hipMemcpyHostToDevice)); CK(hipMemset(dy, 0, ybytes)); CK(hipMemset(dprobe, 0, 136 * 8));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(spp::conv1ab_pool_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spp::C1_SMEM_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(spp::conv1ab_pool_f16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spp::C1_SMEM_BYTES));
     const int NT = (H / 2) * ((W + 63) / 64), per = (NT + 7) / 8;
     spp::PadPlanes pp = {};                       // no planes: C = 0
     hipEvent_t e0, e1;
@@ -37,8 +37,8 @@ int main(int argc, char** argv) {
     float* yout = dy + spp::feat_guard(L2);
     for (int it = 0; it < 5; ++it) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(spp::conv1ab_pool_f16_kernel, dim3(8 * std::min(per, 64)), dim3(512), spp::C1_SMEM_BYTES, 0, dimg, dw, db, dwp, dbias,
-                           yout, L1, L2, pp, delay, abl, dprobe);
+        hipLaunchKernelGGL((spp::conv1ab_pool_f16_kernel<true, true>), dim3(8 * std::min(per, 64)), dim3(512), spp::C1_SMEM_BYTES, 0, dimg, dw, db, dwp, dbias,
+                           yout, L1, L2, 64, pp, delay, abl, dprobe);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
