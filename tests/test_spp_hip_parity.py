@@ -364,9 +364,11 @@ def test_random_shapes_dense_and_keypoints(seed):
             np.testing.assert_allclose(np.linalg.norm(d, axis=0), 1.0, atol=1e-5)
 
 
-def test_batch_of_full_size_crops_is_per_image_identical():
-    """Four 512x512 crops in one launch sequence: every image's result is bit-identical to running it alone."""
-    mod, _ = make_module(0, {"nms_radius": 3, "max_keypoints": 4096})
+@pytest.mark.parametrize("precision", SPP_PRECISIONS)
+def test_batch_of_full_size_crops_is_per_image_identical(precision):
+    """Four 512x512 crops in one launch sequence: every image's result is bit-identical to running it alone (under fp16x4 this is
+    the batched form of the resident-block kernels: first layer, conv2a, conv2b, conv3a)."""
+    mod, _ = make_module(0, {"nms_radius": 3, "max_keypoints": 4096}, precision=precision)
     img = torch.from_numpy(synthetic.make_image(4, 512, 512, 31)).cuda()
     kp, sc, de, cnt = mod.forward_device(img)
     for i in (0, 3):
