@@ -502,15 +502,20 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
     };
     // the loaded form: position j of the block is X[ch][im][(2 yp + r) * Wp + 64 sx + x] (padded coordinates: the plane's zero ring is
     // the halo); a lane owns 16 channels of its position: 16 loads (each coalesced over the wave's positions), 8 splits, 2 + 2 16-byte stores
-    auto load_tile = [&](int tt, int cc, int im, int yp, int sx) {
+    // two phases, so that the loads of channel slab 1 can be in flight while slab 0 is multiplied
+    auto load_issue = [&](int tt, int cc, int im, int yp, int sx, float (&v)[16]) {
+        int j = 32 * tt + l31;
+        asm volatile("" : "+v"(j));
+        j = min(j, C1_COLS - 1);                           // lanes past the block re-read its last position (not stored)
+        const int r = j / C1_BW, x = j - r * C1_BW;
+        const float* src = img + (size_t)im * L.ld + (size_t)(2 * yp + r) * L.Wp + 64 * sx + x + (size_t)(cc * 32 + 16 * half) * L.ldt;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = src[(size_t)i * L.ldt];
+    };
+    auto load_commit = [&](int tt, const float (&v)[16]) {
         int j = 32 * tt + l31;
         asm volatile("" : "+v"(j));
         if (j >= C1_COLS) return;
-        const int r = j / C1_BW, x = j - r * C1_BW;
-        const float* src = img + (size_t)im * L.ld + (size_t)(2 * yp + r) * L.Wp + 64 * sx + x + (size_t)(cc * 32 + 16 * half) * L.ldt;
-        float v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = src[(size_t)i * L.ldt];
         unsigned hi[8], lo[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) gatsspg::fp16_split2(v[2 * i], v[2 * i + 1], hi[i], lo[i]);
@@ -520,12 +525,28 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
         *reinterpret_cast<u32x4*>(Blo + o) = (u32x4){lo[0], lo[1], lo[2], lo[3]};
         *reinterpret_cast<u32x4*>(Blo + o + 8) = (u32x4){lo[4], lo[5], lo[6], lo[7]};
     };
+    // the eight positions past the eighth tile (block row 3, x = 58 .. 65) x 32 channels: one value per thread of waves 0-3
+    auto tail_issue = [&](int cc, int im, int yp, int sx) -> float {
+        if (tid >= 256) return 0.f;
+        return img[(size_t)im * L.ld + (size_t)(2 * yp + 3) * L.Wp + 64 * sx + 58 + (tid & 7) + (size_t)(cc * 32 + (tid >> 3)) * L.ldt];
+    };
+    auto tail_commit = [&](float v) {
+        if (tid >= 256) return;
+        unsigned h, l;
+        gatsspg::fp16_split2(v, 0.f, h, l);
+        const int o = (256 + (tid & 7)) * C1_KS + (tid >> 3);
+        Bhi[o] = (unsigned short)h;
+        Blo[o] = (unsigned short)l;
+    };
     // 264 positions = 8 tiles of 32 + 8: wave w builds tile w, wave 0 also the tail
     auto make_block = [&](int cc, int im, int yp, int sx) {
         C1_STAMP();
         if constexpr (!C1A) {
-            load_tile(wave, cc, im, yp, sx);
-            if (wave == 7) load_tile(8, cc, im, yp, sx);
+            float v[16];
+            load_issue(wave, cc, im, yp, sx, v);
+            const float tv = tail_issue(cc, im, yp, sx);
+            load_commit(wave, v);
+            tail_commit(tv);
             C1_STAMP();
             return;
         }
@@ -693,6 +714,11 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
         if constexpr (C1A) pix = gload_patch(nitem, more); // the next patch's pixel: in flight until the staging interval after group 4
         // interval 0: resident block of channel slab 0 (the A slabs of group 0 are in the buffer)
         if (!(abl & 1)) make_block(0, im, yp, sx);
+        float nv[16], nvt = 0.f;                           // loaded form: slab 1 of this wave's tile (+ tail value), requested three groups ahead
+        if constexpr (!C1A) {
+            load_issue(wave, 1, im, yp, sx, nv);
+            nvt = tail_issue(1, im, yp, sx);
+        }
         gload_a(1, rt, ra);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -709,7 +735,13 @@ __global__ __launch_bounds__(512, 4) void conv1ab_pool_f16_kernel(const float* _
             if (grp == 5) break;
             swrite_a(ra);
             asm volatile("" ::: "memory");
-            if (grp == 2 && !(abl & 1)) make_block(1, im, yp, sx);
+            if (grp == 2 && !(abl & 1)) {
+                if constexpr (C1A) make_block(1, im, yp, sx);
+                else {
+                    load_commit(wave, nv);
+                    tail_commit(nvt);
+                }
+            }
             if constexpr (C1A) {
                 if (grp == 4 && tid < 6 * 68) patch[tid] = pix;    // block 1 is built: the next patch's pixels
             }
