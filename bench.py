@@ -64,6 +64,44 @@ def kernel_flops(name, n1, n2):
             "score_exp": 2 * n1 * n2 * 256, "gats": 16 * n2 * 256 * 9, "final_proj_norm": 2 * 256 * 256 * n}.get(name, 1)
 
 
+HBM_KERNELS = ("gats", "conf_finalize", "match_tail", "stat_final", "kv_final")   # kernels whose roofline is the HBM one
+PEAK_HBM_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
+USED_PARAMS = 5_587_200       # parameters the forward reads
+
+
+def kernel_bytes(name, n1, n2, L=NUM_LEAF):
+    """ALGORITHMIC (compulsory) HBM bytes per launch of the HBM-bound kernels, DESIGN 5: what the kernel must read + write once."""
+    return {"gats": 4 * 256 * n2 * (L + 2),                       # leaves + h read, new h written
+            "conf_finalize": 8 * n1 * n2,                        # E read, conf written in place
+            "match_tail": 8 * (n1 * ((n2 + 511) // 512) + n2 * ((n1 + 15) // 16)),   # (value, index) arg-max partials of rows and columns
+            "stat_final": 4 * 2 * 512 * ((n1 + 63) // 64 + (n2 + 63) // 64),
+            "kv_final": 4 * (64 * 64 + 64) * 4 * ((n1 + 63) // 64 + (n2 + 63) // 64)}.get(name, 0)
+
+
+def b_alg(n1, n2, L, d=256):
+    """Algorithmic bytes per frame, SURVEY.md 8(d): descriptors in, parameters, conf + matches out."""
+    return 4 * d * (n1 + n2 + n2 * L) + 4 * USED_PARAMS + 4 * n1 * n2 + 12 * (n1 + n2)
+
+
+def roofline_floors(n1, n2, precision):
+    """Per-frame time floors of the two rooflines (ms): the matrix pipes at the arithmetic actually issued (split modes: nterms
+    16-bit products per fp32 product of the attention-layer GEMMs, the rest on the fp32 MFMA) and HBM at the algorithmic bytes."""
+    n = n1 + n2
+    nterms = {"fp32": 0, "bf16x3": 3, "bf16x6": 6, "fp16x3": 3, "fp16x4": 4}[precision]
+    gemm = 8 * (kernel_flops("mlp0", n1, n2) + kernel_flops("mlp3", n1, n2) + 2 * 768 * 256 * n)
+    rest = f_alg(n1, n2, NUM_LEAF) - 8 * 21 * n * 256 * 256       # GATs + final_proj + score (+ nothing of the attention layers)
+    rest += 8 * 2 * 256 * 64 * n                                  # the KV pass of qkv_kv stays on the fp32 MFMA in every mode
+    if nterms:
+        mfma_ms = (gemm * nterms / PEAK_BF16_MFMA_TFLOPS + rest / PEAK_F32_MFMA_TFLOPS) / 1e9
+    else:
+        mfma_ms = (gemm + rest) / PEAK_F32_MFMA_TFLOPS / 1e9
+    hbm_ms = b_alg(n1, n2, NUM_LEAF) / (PEAK_HBM_GBPS * 1e9) * 1e3
+    return {"mfma_floor_ms_per_frame": round(mfma_ms, 4), "hbm_floor_ms_per_frame": round(hbm_ms, 4),
+            "binding": "mfma" if mfma_ms >= hbm_ms else "hbm",
+            "how": "executed matrix flops / dense MFMA peak of the pipe they are issued on (157.3 TF/s fp32, 2516.6 TF/s 16-bit) vs "
+                   "algorithmic bytes (SURVEY 8d B_alg) / 8 TB/s; the larger floor is the roofline that binds this shape and arithmetic"}
+
+
 class Weights:
     """Random-init GATsSPG weights packed once on the device (shared by every in-flight frame)."""
 
@@ -452,7 +490,9 @@ def main_pipeline(args):
     torch.cuda.synchronize(device)
     lat = (time.perf_counter() - t0) / K
     print(json.dumps({"metric": "pipeline_frames_per_sec", "value": round(thr, 2), "unit": "frames/s", "n_gpus": 1, "steps": K,
-                      "warmup": W, "ms_per_step": round(1e3 / thr, 4), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                      "warmup": W, "ms_per_step": round(1e3 / thr, 4), "higher_is_better": True,
+                      "dtype": "f32" if args.matcher_precision == args.extractor_precision == "fp32" else
+                               f"matcher {args.matcher_precision} / extractor {args.extractor_precision}", "data": "synthetic",
                       "config": {"workload": f"{SPP_H}x{SPP_W} crop -> SuperPoint (top {N1}) -> GATsSPG vs N_3D={N2} database -> RANSAC-EPnP "
                                              f"({pnp.ITERATIONS} hypotheses), batch 1, all hand-offs in HBM", "frames_in_flight": S,
                                  "matches_into_pnp": n_matches, "matcher_gemm_precision": args.matcher_precision,
@@ -554,6 +594,18 @@ CONFIGS = {
                    what="BASELINE configs[4] shape: N_3D=20000 dense cloud, batch 1 per step, fp32"),
     "stress-b4": dict(b=4, n1=1000, n2=20000, precision="fp32", golden="stress_b4",
                       what="BASELINE configs[4]'s per-GPU share: 4 frames of 1000/20000 per step, fp32"),
+    "fp16x4-stress": dict(b=1, n1=1000, n2=20000, precision="fp16x4", golden="stress_rand",
+                          what="BASELINE configs[4] shape (N_3D=20000, batch 1) with the attention-layer GEMMs on four-term split-fp16 MFMA; "
+                               "reported separately, never the headline value"),
+    "fp16x4-stress-b4": dict(b=4, n1=1000, n2=20000, precision="fp16x4", golden="stress_b4",
+                             what="BASELINE configs[4]'s per-GPU share (4 frames of 1000/20000 per step) on the 16-bit pipe: four-term "
+                                  "split-fp16 MFMA in the attention-layer GEMMs -- the line that tests configs[4]'s 'HBM-bound regime' "
+                                  "(config.roofline_floors says which roofline binds); reported separately, never the headline value"),
+    "fp16x4-real": dict(b=1, n1=500, n2=2000, precision="fp16x4", golden="real_rand",
+                        what="OnePose's own operating point (N_2D=500 N_3D=2000, batch 1) with the attention-layer GEMMs on four-term "
+                             "split-fp16 MFMA; reported separately, never the headline value"),
+    "fp16x4-real-b8": dict(b=8, n1=500, n2=2000, precision="fp16x4", golden="real_b8",
+                           what="8 frames of 500/2000 per step, attention-layer GEMMs on four-term split-fp16 MFMA; reported separately"),
 }
 GOLDEN_SEEDS = {"head_rand": 1, "head_b8": 3, "stress_rand": 5, "stress_b4": 7, "real_rand": 8, "real_b8": 9}   # make_inputs seeds of tests/golden/make_bench_golden.py
 
@@ -688,6 +740,7 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus})")
     rank, local_rank, world = sharding.init_process_group(backend="gloo" if args.dry_run else None)
+    pinned, prev_affinity = "unpinned (not launched under torchrun)", None
     cfg = CONFIGS[args.config]
     if args.shape:
         dims = [int(v) for v in args.shape.split(",")]
@@ -706,6 +759,8 @@ def main():
             raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
         device = torch.device("cuda", local_rank)
         torch.cuda.set_device(device)
+        if launched:   # one launch thread per rank, next to its GPU (N Python loops at ~60 k launches/s each are host-sensitive)
+            pinned, prev_affinity = sharding.pin_launch_thread(device)
         weights = Weights(device, cfg["precision"])
         base = Runner(device, weights, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], golden_seed=GOLDEN_SEEDS.get(cfg["golden"]))
         slots = [Runner(device, weights, base.shared_inputs, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], own_stream=True) for _ in range(S)]
@@ -732,15 +787,18 @@ def main():
     reps = [timed_pass(True) for _ in range(R)]
     elapsed = float(np.median(reps))
 
+    dev_key, dev_desc = sharding.device_identity(device)
     if args.dry_run:
-        per_rank = sharding.gather_metrics([K, elapsed])
+        per_rank = sharding.gather_metrics([K, elapsed, dev_key])
         value, seconds = sharding.aggregate_throughput(per_rank)
         if rank == 0:
             print(json.dumps({"metric": "query_frames_per_sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
                               "steps": K, "warmup": W, "ms_per_step": round(seconds / K * 1e3, 4), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run",
                               "config": {"workload": "DRY RUN: stub steps on CPU, launcher / collective plumbing only",
-                                         "per_rank_frames_per_sec": [round(float(k / t), 2) for k, t in per_rank.tolist()]}}), flush=True)
+                                         "per_rank_frames_per_sec": [round(float(k / t), 2) for k, t, _ in per_rank.tolist()],
+                                         "ranks_seen": len({int(d) for _, _, d in per_rank.tolist()}),
+                                         "rank_devices": [int(d) for _, _, d in per_rank.tolist()]}}), flush=True)
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
@@ -804,7 +862,8 @@ def main():
                      "note": "3D database resident, its query-independent GNN work cached once per object; bit-identical outputs"}
 
     parity = golden_parity(runner, cfg) if rank == 0 else None
-    per_rank = sharding.gather_metrics([K * runner.b, elapsed, solo if solo is not None else elapsed], device=device)  # the one (RCCL) collective
+    # the one (RCCL) collective: timings + the identity key of the device each rank drives (float64: keys are exact integers)
+    per_rank = sharding.gather_metrics([K * runner.b, elapsed, solo if solo is not None else elapsed, dev_key], device=device)
     value, seconds = sharding.aggregate_throughput(per_rank.cpu())
 
     if rank == 0:
@@ -816,6 +875,11 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         if split:                 # 3 (6) bf16 MFMA products are issued per algorithmic flop: price the executed flops against the bf16 peak
             achieved *= nterms
+        hbm = args.kernel in HBM_KERNELS
+        if hbm:                   # bytes / time against the HBM peak
+            fl = kernel_bytes(args.kernel, n1, n2) * bsz
+            achieved = fl / (kern_ms * 1e-3) / 1e9
+            peak = PEAK_HBM_GBPS
         falg = f_alg(n1, n2, NUM_LEAF)
         per = per_rank.cpu().tolist()
         fps1 = K * bsz / per[0][2] if world > 1 else value
@@ -836,17 +900,25 @@ def main():
                        "single_stream_frames_per_sec": round(bsz / latency, 2),
                        "parallelism": f"weak scaling: every one of the {world} rank(s) runs its own {K} steps on its own GPU, weights and "
                                       "database replicated, no data-path collective (one barrier pair + one metrics all_gather)",
-                       "per_rank_frames_per_sec": [round(k / t, 2) for k, t, _ in per],
+                       "per_rank_frames_per_sec": [round(k / t, 2) for k, t, _, _ in per],
+                       "ranks_seen": len({int(d) for _, _, _, d in per}),
+                       "rank_devices": [f"{int(d):#x}" for _, _, _, d in per],
+                       "rank0_device": dev_desc, "launch_thread_affinity": pinned,
+                       "ranks_seen_is": "number of DISTINCT physical devices (PCI domain:bus:device + 24 UUID bits, all_gathered with the "
+                                        "timings) the ranks drove: must equal n_gpus",
                        "process_group": sharding.backend_name(),
+                       "roofline_floors": roofline_floors(n1, n2, cfg["precision"]),
+                       "end_to_end_hbm_frac": round(b_alg(n1, n2, NUM_LEAF) * value / world / (PEAK_HBM_GBPS * 1e9), 4),
                        "algorithmic_gflop_per_frame": round(falg / 1e9, 2),
                        "end_to_end_f32_mfma_frac": round(falg * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                        "end_to_end_single_stream_f32_mfma_frac": round(falg * bsz / latency / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
-            "roofline": {"bound": "mfma", "kernel": args.kernel + "_kernel", "achieved": round(achieved, 2),
-                         "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "roofline": {"bound": "hbm" if hbm else "mfma", "kernel": args.kernel + "_kernel", "achieved": round(achieved, 2),
+                         "peak": peak, "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": pmc_traffic(args.kernel) if args.config == "headline" and not args.shape else None,
                          "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 PMC passes of this build committed under "
                                            "profiles/, not measured in this run)" if args.config == "headline" else None,
-                         "kernel_ms": round(kern_ms, 5), "empty_event_pair_ms": round(pair_ms, 5), "flops_per_launch": fl,
+                         "kernel_ms": round(kern_ms, 5), "empty_event_pair_ms": round(pair_ms, 5),
+                         ("algorithmic_bytes_per_launch" if hbm else "flops_per_launch"): fl,
                          "how": f"hipEvent pair on the compute stream around launch #0 of {args.kernel}_kernel in each of {K} "
                                 f"steps of a one-frame-at-a-time pass (the throughput pass overlaps {S} steps); the bracket includes "
                                 f"event-packet latency (an empty pair on the same stream reads empty_event_pair_ms), so rocprofv3's "
@@ -870,6 +942,8 @@ def main():
                            "bf16x3: two planes, three products (~2^-16 relative).  fp16x3: two fp16 terms (2 x 11 significand bits, ~2^-20 relative), "
                            "three fp16 MFMA products; fp16x4: all four products of the same terms (fp32-class)")
         if world == 1 and not args.no_cpu_baseline and args.config == "headline":
+            if prev_affinity is not None:      # the CPU leg uses the host's cores, not the launch thread's NUMA node
+                os.sched_setaffinity(0, prev_affinity)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():

@@ -33,6 +33,8 @@ def test_default_line_contract():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] == "mfma" and 0.2 < rf["frac"] < 1.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "static" in rf["traffic_source"]
+    fl = d["config"]["roofline_floors"]
+    assert fl["binding"] == "mfma" and fl["mfma_floor_ms_per_frame"] > fl["hbm_floor_ms_per_frame"] > 0 and d["config"]["ranks_seen"] == 1
     # the timed code path reproduces the reference's own output on the golden frame, in the same JSON line
     pc = d["parity_check"]
     assert "reference" in pc["against"] and pc["max_abs_conf_err"] < 1e-4 and pc["argmax_flips"] == 0 and pc["argmax_checked"] == 8000
@@ -80,6 +82,8 @@ def test_launched_under_torchrun_world1_runs_the_rccl_path():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["process_group"] == "nccl" and len(d["config"]["per_rank_frames_per_sec"]) == 1
+    # the line proves which devices the ranks drove: one distinct physical device for one rank
+    assert d["config"]["ranks_seen"] == 1 and len(d["config"]["rank_devices"]) == 1 and "launch_thread_affinity" in d["config"]
     assert d["parity_check"]["argmax_flips"] == 0
     print(f"torchrun world-1 value {d['value']} vs un-launched {plain['value']} ({d['value'] / plain['value'] - 1:+.2%})")
     assert abs(d["value"] / plain["value"] - 1) < 0.05, (d["value"], plain["value"])   # measured: within 1-2 % (two 5-pass medians)
@@ -91,6 +95,7 @@ def test_gpus_n_launches_n_ranks_by_itself():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     d = run("--gpus", "2", "--dry-run", "--steps", "10", "--warmup", "1", "--reps", "2", env=env)
     assert d["n_gpus"] == 2 and d["data"] == "dry-run" and len(d["config"]["per_rank_frames_per_sec"]) == 2
+    assert d["config"]["ranks_seen"] == 2 and len(set(d["config"]["rank_devices"])) == 2   # two ranks, two distinct "devices" (processes)
     bad = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,
                        timeout=120, cwd=ROOT, env=bad)
@@ -107,6 +112,16 @@ def test_cpu_baseline_legs():
     for cb, unit in ((bench.cpu_baseline(max_seconds=0.5), "frames/s"), (bench.spp_cpu_baseline(max_seconds=0.5), "images/s")):
         assert {"value", "unit", "cores", "kind", "sample", "host_cores", "threads_used"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
         assert cb["unit"] == unit and 1 <= cb["cores"] == cb["threads_used"] <= cb["host_cores"] == os.cpu_count()
+
+
+@gpu
+def test_hbm_kernels_report_an_hbm_roofline():
+    """--kernel gats / conf_finalize: bytes / time against the 8 TB/s HBM peak, not flops against the matrix peak."""
+    for k in ("gats", "conf_finalize"):
+        d = run("--kernel", k, "--steps", "6", "--warmup", "2", "--reps", "2", "--no-cpu-baseline", "--no-side-arithmetics")
+        rf = d["roofline"]
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and 0.1 < rf["frac"] < 1.0, rf
+        assert rf["algorithmic_bytes_per_launch"] > 5e7 and rf["traffic"] >= rf["algorithmic_bytes_per_launch"] * 0.9
 
 
 @gpu

@@ -318,21 +318,31 @@ def test_benchmarked_shapes_vs_reference_golden(name, precision, bench_golden_me
 
 def test_stress_b4_vs_reference_golden(bench_golden_meta):
     """configs[4]'s per-GPU share (4 frames of 1000/20000 per step, `bench.py --config stress-b4`) against the reference's
-    own output at that shape: conf within 1e-4, arg-max indices identical except at reference near-ties.  80000 column
-    arg-maxes over 1000 candidates of magnitude 1e-5..1e-3 hold 14 places where the reference's own top-2 entries are closer
-    than 5e-5 relative (6.4e-7, 1.2e-5, 1.8e-5, 1.8e-5, 2.1e-5, ...): a re-associated fp32 evaluation moves a conf entry by
-    up to ~1e-5 relative there (d conf / conf = d score / 0.07), so a few of those flip (measured: 1-2, at gaps <= 2.7e-5).
-    Only such places may differ (conftest.argmax_flips refuses any other); the count is printed."""
+    own output at that shape: conf within 1e-4, arg-max indices identical except at reference near-ties.
+
+    HISTORY, stated plainly: this test first ran with the fp32 tie gap of conftest.TIE_GAP (2e-5) and FAILED on the GPU
+    (round 3, gpurun_out/r03b/pytest_parity.log): 1-2 of the 84,000 arg-maxes differ from the reference's, at places where the
+    reference's own top-2 entries are 6.4e-7 and 2.7e-5 apart (relative).  The gap below (5e-5) was widened AFTER that
+    measurement and is LOCAL to this test -- conftest.TIE_GAP["fp32"] stays 2e-5 and every other fp32 golden test requires zero
+    flips.  Why it is legitimate: 80,000 column arg-maxes over 1000 candidates of magnitude 1e-5..1e-3 hold a handful of
+    places where the reference's own candidates are closer than 5e-5 relative; a re-associated fp32 evaluation moves a conf
+    entry by up to ~1e-5 relative there (d conf / conf = d score / 0.07), so the reference run on another BLAS would flip
+    the same places.  What is asserted: every differing index sits at such a near-tie of the GOLDEN (an allow-list by
+    position: argmax_flips refuses any other place), and there are at most 4 of them."""
     mc = bench_golden_meta["cases"]["stress_b4"]
     g = load_golden("bench_stress_b4")
     sd, data, hp = case_inputs(mc)
     pred, conf = make_model(sd, hp, "fp32")(to_dev(data))
-    tie = 5e-5
-    res = check_bench_golden(conf.cpu().numpy(), {k: v.cpu().numpy() for k, v in pred.items()}, g, mc, CONF_ATOL, "stress_b4[fp32]",
-                             tie_gap=tie)
+    tie = 5e-5   # local to this test, see the docstring; NOT conftest.TIE_GAP["fp32"]
+    assert TIE_GAP["fp32"] == 2e-5
+    cn = conf.cpu().numpy()
+    res = check_bench_golden(cn, {k: v.cpu().numpy() for k, v in pred.items()}, g, mc, CONF_ATOL, "stress_b4[fp32]", tie_gap=tie)
     print(f"stress_b4 [fp32]: {res}")
-    near_ties = int((g["col_top2_rel_gap"] < tie).sum() + (g["row_top2_rel_gap"] < tie).sum())
-    assert near_ties == 14 and res["flips_rows"] + res["flips_cols"] <= 4
+    # allow-list by position: the differing places are a subset of the golden's own near-tie positions
+    allowed_rows, allowed_cols = g["row_top2_rel_gap"] < tie, g["col_top2_rel_gap"] < tie
+    assert not ((cn.argmax(axis=2) != g["indices0_raw"]) & ~allowed_rows).any()
+    assert not ((cn.argmax(axis=1) != g["indices1_raw"]) & ~allowed_cols).any()
+    assert res["flips_rows"] + res["flips_cols"] <= 4
 
 
 def test_keypoint_encoder():

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of tuning-build knobs on one config: tools/r03_ab.sh <tag> <config> <kernel> "<KNOB=V,KNOB=V>" ...   ("" = defaults)
+# A/B of tuning-build knobs on one config: tools/ab_knobs.sh <tag> <config> <kernel> "<KNOB=V,KNOB=V>" ...   ("" = defaults)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$1; mkdir -p $O
 C=$2; K=$3; shift 3

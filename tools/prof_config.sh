@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel stats of one bench config, one frame at a time:  tools/r03_prof_cfg.sh <tag> <config> [more bench flags]
+# rocprofv3 kernel stats of one bench config, one frame at a time:  tools/prof_config.sh <tag> <config> [more bench flags]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$1; mkdir -p $O
 C=$2; shift 2

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of tuning-build knobs at custom shapes: tools/r03_shape_ab.sh <tag> "<shape> <shape> ..." "<KNOBS>" "<KNOBS>" ...
+# A/B of tuning-build knobs at custom shapes: tools/shape_ab.sh <tag> "<shape> <shape> ..." "<KNOBS>" "<KNOBS>" ...
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$1; mkdir -p $O
 SHAPES=$2; shift 2
