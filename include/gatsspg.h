@@ -56,12 +56,17 @@ extern "C" {
 #define GATSSPG_FLAG_PREC_BF16X6 0x200
 /*   GATSSPG_FLAG_PREC_FP16X3 / _FP16X4: two-term split on IEEE fp16 -- every fp32 operand is x1 + x2 with x1 = RNE_fp16(x),
  *     x2 = RNE_fp16(x - x1), i.e. 2 x 11 significand bits with a signed remainder (|x - x1 - x2| <= 2^-23 |x|; bf16x3: 2^-16), both
- *     conversions saturating at +-65504 (MODE.FP16_OVFL) so that an out-of-range operand never becomes infinity (operands beyond
- *     +-131008 lose precision; operands below ~0.06 in magnitude keep an absolute error of 6e-8, the fp16 subnormal spacing).
+ *     conversions saturating at +-65504 (MODE.FP16_OVFL) so that an out-of-range operand never becomes infinity.  Every operand is
+ *     multiplied by an EXACT power of two before the split and the accumulators are scaled back (ABI 400), so that the second term
+ *     stays a normal fp16 number for small operands: weights per matrix at pack time (largest entry to [2^13, 2^14): the 2^-23
+ *     bound holds down to |w| ~ 2^-24 max|W|), activations by 2^4 (bound holds down to |x| ~ 2^-7, absolute error 2^-29 below;
+ *     exact two-term range +-8188, saturating beyond), the per-segment message operator by 2^-(ceil(log2 n_source) + 6) of its
+ *     weight scale (its entries grow with the number of source points).
  *     FP16X3: the three leading products on v_mfma_f32_32x32x16_f16 -- the matrix-pipe time of bf16x3 (BASELINE configs[3] names
  *     fp16; a SINGLE fp16 term fails the parity bar like a single bf16 term does).  FP16X4: all four products, the exact product
  *     of the split operands with fp32 accumulation -- fp32-class results in four MFMAs where bf16x6 needs six.  Measured parity in
- *     DESIGN.md 12d / tests/test_hip_parity.py.  The four precision bits are exclusive. */
+ *     DESIGN.md 12d / tests/test_hip_parity.py (test_split_modes_are_scale_invariant: weights of 1e-3 .. 5e-5, activations of 0.003 .. 1).
+ *     The four precision bits are exclusive. */
 #define GATSSPG_FLAG_PREC_FP16X3 0x400
 #define GATSSPG_FLAG_PREC_FP16X4 0x800
 /* layer kinds for gatsspg_attn_layer (GATs_SuperGlue.py:55-64) */

@@ -48,8 +48,11 @@ typedef struct spp_raw_weights {
  *   0 (default): exact fp32 MFMA (v_mfma_f32_32x32x2_f32) -- the reference's arithmetic;
  *   SPP_FLAG_PREC_FP16X4: every fp32 operand as two fp16 terms (RNE, saturating at +-65504), all four products on
  *     v_mfma_f32_32x32x16_f16 with fp32 accumulation -- fp32-class results at a quarter of the matrix-pipe time (the matcher's
- *     GATSSPG_FLAG_PREC_FP16X4; include/gatsspg.h).  conv1a, the detector head's softmax, NMS / top-k and the descriptor sampling
- *     are fp32 in both modes.  Unknown bits are refused. */
+ *     GATSSPG_FLAG_PREC_FP16X4; include/gatsspg.h).  conv1a: fp32 VALU in the default mode and for odd H; under
+ *     SPP_FLAG_PREC_FP16X4 with even H it is RECOMPUTED inside conv1b's fused kernel (conv1ab_pool_f16_kernel) on the f16 MFMA from
+ *     fp16-split pixels, weights and bias -- the standalone conv1a kernel is then never launched (spp_forward_profiled with its
+ *     kernel id returns an error).  The detector head's softmax, NMS / top-k and the descriptor sampling are fp32 in both modes.
+ *     Operand range of the fp16 terms: see include/gatsspg.h (two-term fp16 splits).  Unknown bits are refused. */
 #define SPP_FLAG_PREC_FP16X4 0x800
 
 int spp_version(void);

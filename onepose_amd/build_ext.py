@@ -18,8 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgatsspg_hip.so")
-SOURCES = ["gatsspg_gemm_kernels.hip", "gatsspg_stream_kernels.hip", "gatsspg_capi.hip"]
-HEADERS = ["gatsspg_common.h", "gatsspg_launch.h", "gemm_f32_mfma.h", os.path.join("..", "..", "include", "gatsspg.h")]
+SOURCES = ["gatsspg_gemm_kernels.hip", "gatsspg_split_kernels.hip", "gatsspg_stream_kernels.hip", "gatsspg_capi.hip"]
+HEADERS = ["gatsspg_common.h", "gatsspg_launch.h", "gemm_f32_mfma.h", "gemm_split_glds.h", os.path.join("..", "..", "include", "gatsspg.h")]
 SPP_LIB_PATH = os.path.join(LIB_DIR, "libspp_hip.so")
 SPP_SOURCES = ["spp_conv_kernels.hip", "spp_detect_kernels.hip", "spp_capi.hip"]
 SPP_HEADERS = ["spp_common.h", "gemm_f32_mfma.h", "gatsspg_common.h", os.path.join("..", "..", "include", "superpoint.h")]

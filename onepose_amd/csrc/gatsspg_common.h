@@ -83,7 +83,10 @@ struct AttnW {  // offsets inside one attention layer block
     static constexpr size_t B0 = W0 + 512 * 512;               // [512] = b0 + W0b @ bm
     static constexpr size_t W3 = B0 + 512;                     // [256][512]
     static constexpr size_t B3 = W3 + 256 * 512;               // [256]
-    static constexpr size_t SIZE = B3 + 256;
+    // [4]: the exact powers of two the fp16 planes of WQKV, W0[:, :256] and W3 are multiplied by before the split (weight_scale_kernel:
+    // the matrix maximum lands in [2^13, 2^14)); [3] spare.  The consumers scale the accumulators back.
+    static constexpr size_t SC = B3 + 256;
+    static constexpr size_t SIZE = SC + 4;
 };
 struct GatsW {
     static constexpr size_t U1 = 0;              // [256] = W @ a[:256]   (leaf logit vector)
@@ -111,7 +114,8 @@ struct AttnWB {
     static constexpr size_t QKV_LO2 = W3_LO + 256 * 512;
     static constexpr size_t W0_LO2 = QKV_LO2 + 768 * 256;
     static constexpr size_t W3_LO2 = W0_LO2 + 512 * 512;
-    // fp16 hi / lo planes (GATSSPG_FLAG_PREC_FP16X3 / _FP16X4): hi = RNE_fp16(w), lo = RNE_fp16(w - hi) (clamped), same slab-major layout
+    // fp16 hi / lo planes (GATSSPG_FLAG_PREC_FP16X3 / _FP16X4) of s * w, s = the matrix's power-of-two scale (AttnW::SC):
+    // hi = RNE_fp16(s w), lo = RNE_fp16(s w - hi), same slab-major layout
     static constexpr size_t QKV_H16 = W3_LO2 + 256 * 512;
     static constexpr size_t QKV_L16 = QKV_H16 + 768 * 256;
     static constexpr size_t W0_H16 = QKV_L16 + 768 * 256;
@@ -139,6 +143,7 @@ struct Workspace {
     float *Mop;                      // [b][512][512]: segment 2f at columns 256..511, segment 2f+1 at columns 0..255 of frame f's block
     unsigned short *Mpl;             // split-bf16 planes of M_t (prec != 0): [nseg][3][8 slabs][512][32]
     float *ksumT;                    // [nseg][4][64]
+    float *zsc;                      // [nseg]: fold factor of the target segment's operator planes = (scale of the W0 planes) / (scale of Mpl), a power of two
     float *rowpart, *colpart, *rs, *cs;
     float *rmax_v, *cmax_v, *rshift, *cshift;   // rshift / cshift: row / column maxima of the max-subtracting dual softmax
     int *rmax_i, *cmax_i;
@@ -179,6 +184,7 @@ inline Workspace carve_workspace(void* base, int b, int n1, int n2) {
     w.Mop = (float*)take(sizeof(float) * (size_t)b * 512 * MOP_LD);
     w.Mpl = (unsigned short*)take(sizeof(unsigned short) * (size_t)w.nseg * 3 * MPL_PLANE);
     w.ksumT = (float*)take(sizeof(float) * (size_t)w.nseg * H * DH);
+    w.zsc = (float*)take(sizeof(float) * (size_t)w.nseg);
     w.statpart = (float*)take(sizeof(float) * (size_t)w.nt64 * 2 * 512);
     w.stats = (float*)take(sizeof(float) * (size_t)w.nseg * 2 * 512);
     w.rowpart = (float*)take(sizeof(float) * (size_t)b * w.sc_nct * L.n1p);

@@ -178,7 +178,8 @@ constexpr int KVF_BLOCKS = 16 * KVF_RS + 1;     // 16 d-row blocks x row halves 
 __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict__ kvpart, const float* __restrict__ kv_src,
                                                         float* __restrict__ kvfin, const float* __restrict__ W0,
                                                         float* __restrict__ Mop, unsigned short* __restrict__ Mpl,
-                                                        float* __restrict__ ksumT, ColLayout L, int cross, int prec, int abl) {
+                                                        float* __restrict__ ksumT, float* __restrict__ zsc, const float* __restrict__ sc,
+                                                        ColLayout L, int cross, int prec, int abl) {
     __shared__ float4 red[16][64];
     __shared__ float4 kvs[64];   // this block's final KV^T rows: [4 d][16 float4 of q]
     if (prec >= 3) fp16_saturate_mode();
@@ -191,6 +192,12 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
     const int frame = seg >> 1, side = seg & 1;
     if (!((L.side_mask >> side) & 1)) return;
     const int tseg = cross ? (seg ^ 1) : seg;
+    // fp16 modes: the operator planes hold sM * M, sM = (scale of the W0 planes) * 2^-(ceil(log2 n_src) + 6): KV sums grow with the
+    // number of source points (the reference's v / n ... * n pair cancels, GATs_SuperGlue.py:74-79), unscaled they leave the fp16 range
+    // beyond a few thousand points.  mlp0 folds heads with z_h * zsc, zsc = (W0 scale) / sM = 2^(ceil(log2 n_src) + 6): exact.
+    const int nsrc = side ? L.n2 : L.n1;
+    const int mexp = (32 - __clz(max(nsrc, 2) - 1)) + 6;
+    const float mscale = prec >= 3 ? sc[1] * __builtin_ldexpf(1.f, -mexp) : 1.f;
     // operator phase: thread = (row pair rp, q quarter qq); lane qq takes the float4s qq, qq + 4, qq + 8, qq + 12 of the 64 q of a
     // row (the 4 lanes of a row read 64 contiguous bytes per load).  The weights do not depend on the reduction: requested first.
     const int rp = (tid >> 2) & 127, qq = tid & 3;
@@ -237,7 +244,10 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
         kvs[el] = tot;
         if (db * 64 + el < KVP4 && rs == 0) {
             *reinterpret_cast<float4*>(kvfin + ((size_t)seg * H + h) * KVP + 4 * e4) = tot;
-            if (ksum_block) *reinterpret_cast<float4*>(ksumT + ((size_t)tseg * H + h) * DH + 4 * el) = tot;   // ksum of the source
+            if (ksum_block) {
+                *reinterpret_cast<float4*>(ksumT + ((size_t)tseg * H + h) * DH + 4 * el) = tot;   // ksum of the source
+                if (h == 0 && el == 0) zsc[tseg] = prec >= 3 ? __builtin_ldexpf(1.f, mexp) : 1.f;
+            }
         }
     }
     if (ksum_block) return;
@@ -289,9 +299,9 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
     } else {
         // split planes in the slab-major layout of the weight planes: (m, k) at ((k / 32) * 512 + m) * 32 + k % 32
         unsigned p0a, p1a, p2a = 0, p0b, p1b, p2b = 0;
-        if (prec >= 3) {   // fp16 terms
-            fp16_split2(o0, o1, p0a, p1a);
-            fp16_split2(o2, o3, p0b, p1b);
+        if (prec >= 3) {   // fp16 terms of the scaled operator
+            fp16_split2(o0 * mscale, o1 * mscale, p0a, p1a);
+            fp16_split2(o2 * mscale, o3 * mscale, p0b, p1b);
         } else {
             bf16_split3(o0, o1, p0a, p1a, p2a);
             bf16_split3(o2, o3, p0b, p1b, p2b);
@@ -790,6 +800,36 @@ __global__ __launch_bounds__(256) void gats_wlt_kernel(const float* __restrict__
     }
 }
 
+// Power-of-two scales of the fp16 planes (AttnW::SC): one block per (matrix, layer); s = 2^(13 - floor(log2 max|w|)) puts the
+// largest entry in [2^13, 2^14) -- a factor 4 below the fp16 maximum -- so that the second fp16 term of an entry stays a normal
+// number down to |w| ~ 2^-24 max|w| (unscaled, every weight below 2^-3 had a subnormal second term: 2^-25 absolute error).
+__global__ __launch_bounds__(1024) void weight_scale_kernel(float* __restrict__ packed) {
+    __shared__ float red[1024];
+    const int m = blockIdx.x, layer = blockIdx.y;
+    float* blk = packed + PW_ATTN + (size_t)layer * AttnW::SIZE;
+    float mx = 0.f;
+    if (m == 0) {
+        for (int e = threadIdx.x; e < 768 * 256; e += 1024) mx = fmaxf(mx, fabsf(blk[AttnW::WQKV + e]));
+    } else if (m == 1) {   // the x half of mlp.0 only: the message half reaches the matrix pipe through the operator planes of kv_final
+        for (int e = threadIdx.x; e < 512 * 256; e += 1024) mx = fmaxf(mx, fabsf(blk[AttnW::W0 + (size_t)(e >> 8) * 512 + (e & 255)]));
+    } else {
+        for (int e = threadIdx.x; e < 256 * 512; e += 1024) mx = fmaxf(mx, fabsf(blk[AttnW::W3 + e]));
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float top = red[0];
+        int e = 0;
+        if (top > 0.f && top < 3.0e38f) e = min(max(13 - ilogbf(top), -40), 60);
+        blk[AttnW::SC + m] = __builtin_ldexpf(1.f, e);
+        if (m == 0) blk[AttnW::SC + 3] = 1.f;
+    }
+}
+
 // one-time split of the three big operators of every attention layer into bf16 hi / lo planes (AttnWB layout)
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ packed, unsigned short* __restrict__ packedb) {
     fp16_saturate_mode();
@@ -801,12 +841,12 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     // planes are stored SLAB-MAJOR: element (m, k) of an [M][K] operator at ((k / 32) * M + m) * 32 + k % 32, so that the
     // 128-row x 32-k slab a workgroup stages per step is 8 KB of consecutive bytes (full 128-byte lines per load instruction
     // instead of 64-byte row pieces 2 * K bytes apart)
-    float x;
+    float x, sx;   // sx: the matrix's fp16 scale (weight_scale_kernel)
     size_t hi, lo, lo2, d, h16, l16;
     auto slab_major = [](size_t i, size_t M, size_t K) { const size_t m = i / K, k = i % K; return ((k >> 5) * M + m) * 32 + (k & 31); };
-    if (e < NQ) { x = src[AttnW::WQKV + e]; d = slab_major(e, 768, 256); hi = AttnWB::QKV_HI + d; lo = AttnWB::QKV_LO + d; lo2 = AttnWB::QKV_LO2 + d; h16 = AttnWB::QKV_H16 + d; l16 = AttnWB::QKV_L16 + d; }
-    else if (e < NQ + N0) { x = src[AttnW::W0 + (e - NQ)]; d = slab_major(e - NQ, 512, 512); hi = AttnWB::W0_HI + d; lo = AttnWB::W0_LO + d; lo2 = AttnWB::W0_LO2 + d; h16 = AttnWB::W0_H16 + d; l16 = AttnWB::W0_L16 + d; }
-    else if (e < NQ + N0 + N3) { x = src[AttnW::W3 + (e - NQ - N0)]; d = slab_major(e - NQ - N0, 256, 512); hi = AttnWB::W3_HI + d; lo = AttnWB::W3_LO + d; lo2 = AttnWB::W3_LO2 + d; h16 = AttnWB::W3_H16 + d; l16 = AttnWB::W3_L16 + d; }
+    if (e < NQ) { x = src[AttnW::WQKV + e]; sx = src[AttnW::SC + 0]; d = slab_major(e, 768, 256); hi = AttnWB::QKV_HI + d; lo = AttnWB::QKV_LO + d; lo2 = AttnWB::QKV_LO2 + d; h16 = AttnWB::QKV_H16 + d; l16 = AttnWB::QKV_L16 + d; }
+    else if (e < NQ + N0) { x = src[AttnW::W0 + (e - NQ)]; sx = src[AttnW::SC + 1]; d = slab_major(e - NQ, 512, 512); hi = AttnWB::W0_HI + d; lo = AttnWB::W0_LO + d; lo2 = AttnWB::W0_LO2 + d; h16 = AttnWB::W0_H16 + d; l16 = AttnWB::W0_L16 + d; }
+    else if (e < NQ + N0 + N3) { x = src[AttnW::W3 + (e - NQ - N0)]; sx = src[AttnW::SC + 2]; d = slab_major(e - NQ - N0, 256, 512); hi = AttnWB::W3_HI + d; lo = AttnWB::W3_LO + d; lo2 = AttnWB::W3_LO2 + d; h16 = AttnWB::W3_H16 + d; l16 = AttnWB::W3_L16 + d; }
     else return;
     const unsigned h = bf16_rne_bits(x);
     const float r1 = x - __uint_as_float(h << 16);
@@ -815,13 +855,14 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     dst[lo] = (unsigned short)m;
     dst[lo2] = (unsigned short)bf16_rne_bits(r1 - __uint_as_float(m << 16));
     unsigned fh, fl;   // fp16 terms: the conversion of the main loop (fp16_split2), so weights and activations split alike
-    fp16_split2(x, 0.f, fh, fl);
+    fp16_split2(x * sx, 0.f, fh, fl);
     dst[h16] = (unsigned short)(fh & 0xFFFFu);
     dst[l16] = (unsigned short)(fl & 0xFFFFu);
 }
 
-void launch_split_weights(const float* packed, unsigned short* packedb, hipStream_t s) {
+void launch_split_weights(float* packed, unsigned short* packedb, hipStream_t s) {
     constexpr size_t N = 768 * 256 + 512 * 512 + 256 * 512;
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(3, 8), dim3(1024), 0, s, packed);
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((N + 255) / 256), 8), dim3(256), 0, s, packed, packedb);
 }
 
@@ -855,21 +896,33 @@ static void launch_qkv_t(const float* Wqkv, const float* bqkv, const unsigned sh
                    w.Q, w.kvpart, w.L);
 }
 
+// fp16 modes run on the LDS-DMA loop only (their planes carry the pack-time scale that only those kernels undo).  The bf16 modes stay
+// on the first form: A/B-timed on one box (profiles/r04_split_loop_ab.txt), mlp0 bf16x3 25.0 (first form) vs 25.2 us, 1866 vs 1842
+// frames/s in flight; bf16x6 34.4 vs 40.9 us, 1397 vs 1285 -- the three-plane stage makes the DMA loop 1.5x the LDS traffic.  Tuning
+// builds switch them with GATSSPG_SPLIT_LOOP_BF16X3 / _BF16X6 = 1.
+bool split_loop_glds(int prec) {
+    static const int b3 = tuning_knob("SPLIT_LOOP_BF16X3", 0), b6 = tuning_knob("SPLIT_LOOP_BF16X6", 0);
+    return prec >= 3 || (prec == 1 && b3 != 0) || (prec == 2 && b6 != 0);
+}
+
 void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s,
                    ProfileHook* hk) {
+    if (split_loop_glds(w.prec)) {
+        // Wqkv is the first member of the layer's AttnW block: its scales sit at AttnW::SC from there
+        launch_qkv_kv_sp(Wqkv - AttnW::WQKV + AttnW::SC, bqkv, wb, w, s, hk);
+        return;
+    }
     static const int tq = tuning_knob("QKV_BTILE", 0);   // tuning builds: 1 = split-bf16 on the 4-wave tile
     if (w.prec == 1 && tq == 1) launch_qkv_t<QkvTileB, 1>(Wqkv, bqkv, wb, w, s, hk);
     else if (w.prec == 1) launch_qkv_t<QkvTileW8, 1>(Wqkv, bqkv, wb, w, s, hk);
     else if (w.prec == 2) launch_qkv_t<QkvTileW8, 2>(Wqkv, bqkv, wb, w, s, hk);
-    else if (w.prec == 3) launch_qkv_t<QkvTileW8, 3>(Wqkv, bqkv, wb, w, s, hk);
-    else if (w.prec == 4) launch_qkv_t<QkvTileW8, 4>(Wqkv, bqkv, wb, w, s, hk);
     else launch_qkv_t<QkvTileW8, 0>(Wqkv, bqkv, wb, w, s, hk);
 }
 
 void launch_kv_final(const float* W0, const Workspace& w, int cross, const float* kv_src, hipStream_t s, ProfileHook* hk) {
     static const int abl = tuning_knob("KVF_ABL", 0);   // tuning builds: timing-only ablations of the operator phase
     GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3(KVF_BLOCKS, w.nseg * H), dim3(1024), 0, s, w.kvpart, kv_src, w.kvfin,
-                   W0, w.Mop, w.Mpl, w.ksumT, w.L, cross, w.prec, abl);
+                   W0, w.Mop, w.Mpl, w.ksumT, w.zsc, W0 - AttnW::W0 + AttnW::SC, w.L, cross, w.prec, abl);
 }
 
 template <class T, int ABL, int PREC>
@@ -905,11 +958,12 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     static const int small_nt0 = tuning_knob("SMALL_NT0", 0), small_nt3 = tuning_knob("SMALL_NT3", 64);
     const bool small0 = w.prec == 0 && active_tiles(w.L) <= small_nt0, small3 = w.prec == 0 && active_tiles(w.L) <= small_nt3;
     (void)t0;
-    if (small0 && t0 == 0) launch_mlp0_t<Mlp0TileS, 0, 0>(W0, b0, wb, w, s, hk);
+    const bool sp = split_loop_glds(w.prec);
+    const float* sc = W0 - AttnW::W0 + AttnW::SC;
+    if (sp) launch_mlp0_sp(sc, b0, wb, w, s, hk);
+    else if (small0 && t0 == 0) launch_mlp0_t<Mlp0TileS, 0, 0>(W0, b0, wb, w, s, hk);
     else if (w.prec == 1) launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, wb, w, s, hk);
     else if (w.prec == 2) launch_mlp0_t<Mlp0TileW8, 0, 2>(W0, b0, wb, w, s, hk);
-    else if (w.prec == 3) launch_mlp0_t<Mlp0TileW8, 0, 3>(W0, b0, wb, w, s, hk);
-    else if (w.prec == 4) launch_mlp0_t<Mlp0TileW8, 0, 4>(W0, b0, wb, w, s, hk);
 #ifdef GATSSPG_PROFILING_BUILD
     else if (t0 == 11) launch_mlp0_t<Mlp0TileW8, 1, 0>(W0, b0, wb, w, s, hk);   // no global loads in the loop
     else if (t0 == 12) launch_mlp0_t<Mlp0TileW8, 2, 0>(W0, b0, wb, w, s, hk);   // no loads, no LDS writes
@@ -918,12 +972,11 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
 #endif
     else launch_mlp0_t<Mlp0TileW8, 0, 0>(W0, b0, wb, w, s, hk);
     GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
-    if (small3 && t3 == 1) launch_mlp3_t<Mlp3TileS, 0, 0>(W3, b3, wb, w, s, hk);
+    if (sp) launch_mlp3_sp(sc, b3, wb, w, s, hk);
+    else if (small3 && t3 == 1) launch_mlp3_t<Mlp3TileS, 0, 0>(W3, b3, wb, w, s, hk);
     else if (w.prec == 1 && t3 == 0) launch_mlp3_t<Mlp3Tile, 0, 1>(W3, b3, wb, w, s, hk);
     else if (w.prec == 1) launch_mlp3_t<Mlp3TileTallW8, 0, 1>(W3, b3, wb, w, s, hk);
     else if (w.prec == 2) launch_mlp3_t<Mlp3TileTallW8, 0, 2>(W3, b3, wb, w, s, hk);
-    else if (w.prec == 3) launch_mlp3_t<Mlp3TileTallW8, 0, 3>(W3, b3, wb, w, s, hk);
-    else if (w.prec == 4) launch_mlp3_t<Mlp3TileTallW8, 0, 4>(W3, b3, wb, w, s, hk);
 #ifdef GATSSPG_PROFILING_BUILD
     else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3, 0>(W3, b3, wb, w, s, hk);   // steady-state loop cut: fixed cost only
 #endif

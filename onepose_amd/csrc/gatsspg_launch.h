@@ -51,13 +51,19 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* p
 void launch_kv_final(const float* W0, const Workspace& w, int cross, const float* kv_src, hipStream_t s, ProfileHook* hk = nullptr);
 void launch_mlp(const float* W0, const float* b0, const float* W3, const float* b3, const unsigned short* packedb,
                 const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+// gatsspg_split_kernels.hip: the same three GEMMs on the LDS-DMA split-16-bit loop (gemm_split_glds.h); sc = the layer's AttnW::SC
+void launch_qkv_kv_sp(const float* sc, const float* bqkv, const unsigned short* packedb, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_mlp0_sp(const float* sc, const float* b0, const unsigned short* packedb, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_mlp3_sp(const float* sc, const float* b3, const unsigned short* packedb, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+// true if the split-precision launch goes to the kernels above (fp16 modes: always; bf16 modes: unless a tuning build says otherwise)
+bool split_loop_glds(int prec);
 void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 // shifted = 0: E = exp(S) into conf + row/col sum partials (|S| <= 80); 1: raw scores S into conf (max-subtracting path)
 void launch_score_exp(const Workspace& w, float* conf, float scale, int shifted, hipStream_t s, ProfileHook* hk = nullptr);
 int score_tile_rows();   // rows / columns of a score tile = what one column / row partial sums over (conf_finalize needs the counts)
 int score_tile_cols();
 void launch_gats_wlt(const float* W, const float* P, const Workspace& w, int add_h, hipStream_t s, ProfileHook* hk = nullptr);
-void launch_split_weights(const float* packed, unsigned short* packedb, hipStream_t s);
+void launch_split_weights(float* packed, unsigned short* packedb, hipStream_t s);   // also writes the fp16 plane scales (AttnW::SC) into `packed`
 
 // gatsspg_stream_kernels.hip
 void launch_load_state(const float* dq, const float* d3, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);

@@ -1,0 +1,499 @@
+// The three big GEMMs of an attention layer on the split-16-bit main loop of gemm_split_glds.h (round 4): qkv_kv, mlp.0 (merge and
+// the linear-attention apply folded in) and mlp.3, for the arithmetics GATSSPG_FLAG_PREC_FP16X4 / _FP16X3 (always) and _BF16X3 /
+// _BF16X6.  Same maths, same buffers and the same epilogues as the fp32 kernels of gatsspg_gemm_kernels.hip
+// (GATs_SuperGlue.py:69-128); what differs is how the operands reach the matrix pipe.
+#include "gemm_split_glds.h"
+#include "gatsspg_launch.h"
+
+namespace gatsspg {
+
+#ifndef GATSSPG_PROFILING_BUILD
+static constexpr unsigned long long* g_trace = nullptr;   // (profiling builds: the buffer of gatsspg_debug_set_trace, tools/trace_sp.py)
+#define SP_TRACE_ON(ptr) false
+#else
+#define SP_TRACE_ON(ptr) ((ptr) != nullptr)
+#endif
+
+template <auto Kernel>
+static void allow_big_lds_sp() {
+    static bool done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+}
+
+// plain hooks: no side work; the first product of the K loop starts from zero (FRESH0) or from the caller's accumulators
+template <bool FRESH0>
+struct SpPlainHooks {
+    static constexpr bool ENABLED = false;
+    template <int I, int TM>
+    __device__ __forceinline__ f32x16 (&target(f32x16 (&acc)[TM]))[TM] { return acc; }
+    template <int I, int P>
+    static constexpr bool fresh() { return FRESH0 && I == 0 && P == 0; }
+    template <int I, int P>
+    __device__ __forceinline__ void bvals(const float (&)[8]) {}
+    template <int I, int TM>
+    __device__ __forceinline__ void in_step(f32x16 (&)[TM]) {}
+};
+
+// this lane's 16 bias values per 32-row MFMA tile (rows 8 k + 4 half + 0..3: four 16-byte loads)
+template <class T>
+__device__ __forceinline__ void load_bias16(const float* b, int row0, int wm, int half, float (&bias)[T::TM][16]) {
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const vf4 b4 = ldg4(b + row0 + (wm * T::TM + tm) * 32 + 8 * k + 4 * half);
+            bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
+        }
+}
+
+// =====================================================================================================
+// K1  QKV projection + KV / ksum partials (qkv_kv_kernel of gatsspg_gemm_kernels.hip on the split loop).
+//     128 x 64 tile on 4 waves (64 x 32 per wave), two stages (48 KiB): three workgroups per CU, so the 756 tiles of the headline
+//     shape are resident at once and every SIMD holds three waves of three different workgroups (no common barrier).
+// =====================================================================================================
+template <int MODE>
+using QkvSpTile = SpTile<128, 2, 2, 2, MODE>;
+
+template <class T>
+__global__ __launch_bounds__(T::THREADS, 3) void qkv_kv_sp_kernel(const float* __restrict__ sc, const float* __restrict__ bqkv,
+                                                                const unsigned short* __restrict__ P0, const unsigned short* __restrict__ P1,
+                                                                const unsigned short* __restrict__ P2, const float* __restrict__ Z,
+                                                                float* __restrict__ Qbuf, float* __restrict__ kvpart, ColLayout L) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    float* smem = reinterpret_cast<float*>(smem_c);
+    if constexpr (T::F16) fp16_saturate_mode();
+    int rt, ct;
+    if (!xcd_tile_map(6, active_tiles(L), rt, ct)) return;
+    ct = global_tile(L, ct);
+    const int c0 = ct * T::BN, ld = L.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    float bias[T::TM][16];
+    load_bias16<T>(bqkv, rt * 128, wm, half, bias);
+    const float inv = T::F16 ? 1.f / (sc[0] * T::ACT_SCALE) : 1.f;
+    f32x16 acc[T::TM][T::TN];
+    const size_t ro = (size_t)rt * 128 * BK;
+    auto apl = [&](int kt, int pl) { return (pl == 0 ? P0 : pl == 1 ? P1 : P2) + ro + (size_t)kt * 768 * BK; };
+    auto bsl = [&](int kt) { return Z + (size_t)kt * BK * ld + c0; };
+    SpPlainHooks<true> hooks;
+    SpNoBx nobx;
+    gemm_mainloop_sp<T, D / BK>(reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx);
+
+    if (rt < 2) {
+#pragma unroll
+        for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][0][r] = elu1_select(fmaf(acc[tm][0][r], inv, bias[tm][r])) + 1.f;
+        store_tile_via_lds<T>(acc, smem, Qbuf + (size_t)rt * 128 * ld + c0, ld, [](int, float v) { return v; });
+        return;
+    }
+    // ---- K_h / V_h tile -> LDS -> KV partial (second MFMA pass, fp32: exact like the fp32 kernel's)
+    const int h = rt - 2;
+    const TileSeg ts = tile_seg(L, c0, T::BN);
+    constexpr int TS = T::BN + 4;
+    static_assert(T::BN == QKV_BN && T::WAVES == 4 && 128 * TS * 4 <= T::RING_BYTES, "one KV partial per 64-column tile, four waves");
+    float* Tl = smem;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);  // 0..63 = K_h channel d, 64..127 = V_h channel q
+            const int col = wn * 32 + l31;
+            float v = fmaf(acc[tm][0][r], inv, bias[tm][r]);
+            const float kf = elu1_select(v) + 1.f;
+            v = row < 64 ? kf : v;
+            v = col >= ts.valid ? 0.f : v;  // pad columns must not enter the sums
+            Tl[row * TS + col] = v;
+        }
+    __syncthreads();
+    {
+        const int qi = wave >> 1, di = wave & 1;
+        f32x16 kv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kv[r] = 0.f;
+        const float4* ap = reinterpret_cast<const float4*>(Tl + (di * 32 + l31) * TS + half * 32);
+        const float4* bp = reinterpret_cast<const float4*>(Tl + (64 + qi * 32 + l31) * TS + half * 32);
+#pragma unroll
+        for (int v4 = 0; v4 < 8; ++v4) {
+            const float4 a = ap[v4], b = bp[v4];
+            kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, kv, 0, 0, 0);
+            kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, kv, 0, 0, 0);
+            kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, kv, 0, 0, 0);
+            kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, kv, 0, 0, 0);
+        }
+        float* out = kvpart + ((size_t)ct * H + h) * KVP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = di * 32 + mfma_row(r, half);
+            out[d * DH + qi * 32 + l31] = kv[r];
+        }
+        {   // ksum[d] = sum_m K[d][m]: 4 lanes per row (16 columns each, fixed order), combined by 2 shuffles
+            const int d = tid >> 2, qtr = tid & 3;
+            const float* kr = Tl + d * TS + qtr * 16;
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) s += kr[m];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            if (qtr == 0) out[DH * DH + d] = s;
+        }
+    }
+}
+
+// =====================================================================================================
+// K4  mlp.0 with merge and the linear-attention apply folded in (mlp0_kernel / AttnFoldHooks of the fp32 path):
+//         u = W0a x + sum_h z_h (.) (M_h Qf_h) + b,   z_h[n] = 1 / (Qf_h[:, n] . ksum_h + 1e-6)
+//     K loop over [x ; Qf]: slabs 0..7 accumulate the x part, slabs 8 + 2h, 9 + 2h head h into one of TWO alternating head
+//     accumulators that start from zero (the first product takes C = 0); head h - 1 is folded into the kept sum with its per-column
+//     z while head h multiplies, so the fold's VALU work never waits for the matrix pipe.  The denominators come from the RAW B
+//     values a lane holds anyway (8 consecutive k of its column per k16 half): 8 FMAs against the source's ksum (an LDS table),
+//     added over the head's four halves in a fixed order, the two lane halves combined by one exchange -- per-lane in exactly the
+//     32x32 C layout the fold needs, no LDS round trip.
+// =====================================================================================================
+template <int TM>
+struct AttnFoldSp {
+    static constexpr bool ENABLED = true;
+    static constexpr int SPLIT = 8;
+    f32x16 hacc[2][TM];
+    float dpart[2];
+    const float* ks;   // LDS: ksum of the source segment [4][64]
+    float zfac;        // (scale of the W0 planes) / (scale of the operator planes): exact power of two (1 in the bf16 modes)
+    int half;
+    template <int I, int TM_>
+    __device__ __forceinline__ f32x16 (&target(f32x16 (&acc)[TM_]))[TM_] {
+        if constexpr (I < SPLIT) return acc;
+        else return hacc[((I - SPLIT) >> 1) & 1];
+    }
+    template <int I, int P>
+    static constexpr bool fresh() { return P == 0 && (I == 0 || (I >= SPLIT && ((I - SPLIT) & 1) == 0)); }
+    template <int I, int P>
+    __device__ __forceinline__ void bvals(const float (&v)[8]) {
+        if constexpr (I >= SPLIT) {
+            constexpr int h = (I - SPLIT) >> 1;
+            const float* k = ks + h * 64 + ((I - SPLIT) & 1) * 32 + P * 16 + 8 * half;
+            const float4 k0 = *reinterpret_cast<const float4*>(k), k1 = *reinterpret_cast<const float4*>(k + 4);
+            float p = v[0] * k0.x;
+            p = fmaf(v[1], k0.y, p); p = fmaf(v[2], k0.z, p); p = fmaf(v[3], k0.w, p);
+            p = fmaf(v[4], k1.x, p); p = fmaf(v[5], k1.y, p); p = fmaf(v[6], k1.z, p); p = fmaf(v[7], k1.w, p);
+            if constexpr (((I - SPLIT) & 1) == 0 && P == 0) dpart[h & 1] = p;
+            else dpart[h & 1] += p;
+        }
+    }
+    template <int HD>
+    __device__ __forceinline__ void fold(f32x16 (&kept)[TM]) {
+        float d = dpart[HD & 1];
+        const float o = __shfl_xor(d, 32);
+        d = half ? o + d : d + o;   // lane half 0's partial first on both halves
+        const float z = zfac / (d + 1e-6f);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kept[tm][r] = fmaf(z, hacc[HD & 1][tm][r], kept[tm][r]);
+    }
+    // head h - 1 is folded beside the first products of head h (its own products were issued a whole slab earlier)
+    template <int I, int TM_>
+    __device__ __forceinline__ void in_step(f32x16 (&acc)[TM_]) {
+        if constexpr (I >= SPLIT + 2 && ((I - SPLIT) & 1) == 0) fold<((I - SPLIT) >> 1) - 1>(acc);
+    }
+};
+
+template <int MODE>
+using Mlp0SpTileW = SpTile<128, 2, 4, 3, MODE>;   // 128 x 128 on 8 waves: 252 workgroups at the headline shape, one per CU, 96 KiB ring
+template <int MODE>
+using Mlp0SpTileN = SpTile<128, 2, 2, 3, MODE>;   // 128 x 64 on 4 waves: twice the workgroups (small shapes), two per CU
+template <int MODE>
+using Mlp0SpTileT = SpTile<128, 1, 4, 3, MODE>;   // 128 x 128 on 4 waves, 128 x 32 per wave (one wave per SIMD, every B value split once)
+
+template <class T, int ABL = 0, int SCHED = 0>
+__global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : 2)) void mlp0_sp_kernel(const float* __restrict__ sc, const float* __restrict__ b0,
+                                                              const unsigned short* __restrict__ P0, const unsigned short* __restrict__ P1,
+                                                              const unsigned short* __restrict__ P2, const float* __restrict__ Z,
+                                                              const float* __restrict__ Qbuf, const unsigned short* __restrict__ Mpl,
+                                                              const float* __restrict__ ksumT, const float* __restrict__ zsc,
+                                                              float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
+                                                              unsigned long long* trace) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    float* smem = reinterpret_cast<float*>(smem_c);
+    if constexpr (T::F16) fp16_saturate_mode();
+    SpTrace tr;
+    const unsigned long long t_entry = SP_TRACE_ON(trace) ? __builtin_readcyclecounter() : 0;
+    const unsigned long long w_entry = SP_TRACE_ON(trace) ? wall_clock64() : 0;   // 100 MHz constant clock: calibrates the s_memtime ticks
+    int rt, ct;
+    constexpr int TPW = T::BN / MLP0_BN;   // 64-column tiles (= InstanceNorm partials) per workgroup
+    constexpr int MT = 512 / T::BM;
+    if (!xcd_tile_map(MT, active_tiles(L) / TPW, rt, ct)) return;
+    ct = global_tile(L, ct * TPW) / TPW;   // windows and segments are multiples of 128 columns
+    const int c0 = ct * T::BN, ld = L.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    const TileSeg ts = tile_seg(L, c0, T::BN);
+    // ksum of the source segment -> LDS table behind the ring (published by the first barrier of the main loop)
+    float* tab = reinterpret_cast<float*>(smem_c + T::RING_BYTES);
+    if (tid < 64) reinterpret_cast<vf4*>(tab)[tid] = ldg4(ksumT + (size_t)ts.seg * H * DH + 4 * tid);
+    // requested before the main loop (behind it the two dependent round trips would sit on the critical path: measured 3.9 k cycles of
+    // a 39 k-cycle kernel); hipcc parks some of the 32 values in scratch across the loop, which costs two scratch instructions each
+    float bias[T::TM][16];
+    load_bias16<T>(b0, rt * T::BM, wm, half, bias);
+    const float inv = T::F16 ? 1.f / (sc[1] * T::ACT_SCALE) : 1.f;
+    f32x16 acc[T::TM][T::TN];
+    const size_t ro = (size_t)rt * T::BM * BK;   // slab-major planes: (m, k) at ((k / 32) * 512 + m) * 32 + k % 32
+    const unsigned short* Mh = Mpl + (size_t)ts.seg * 3 * MPL_PLANE + ro;
+    auto apl = [&](int kt, int pl) {
+        return kt < 8 ? (pl == 0 ? P0 : pl == 1 ? P1 : P2) + ro + (size_t)kt * 512 * BK : Mh + (size_t)pl * MPL_PLANE + (size_t)(kt - 8) * 512 * BK;
+    };
+    auto bsl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : Qbuf + (size_t)(kt - 8) * BK * ld) + c0; };
+    AttnFoldSp<T::TM> hooks;
+    hooks.ks = tab; hooks.zfac = zsc[ts.seg]; hooks.half = half;
+    SpNoBx nobx;
+    gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), AttnFoldSp<T::TM>, SpNoBx, ABL, SCHED>(
+        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx, SP_TRACE_ON(trace) ? &tr : nullptr);
+    if (SP_TRACE_ON(trace)) tr.t[9] = __builtin_readcyclecounter();    // behind the loop's last barrier
+    hooks.template fold<3>(reinterpret_cast<f32x16(&)[T::TM]>(acc));
+    if constexpr (ABL & 32) {   // timing only: no epilogue at all (one store keeps the accumulators alive)
+        if (acc[0][0][0] == 123.456f) U[0] = acc[T::TM - 1][0][5];
+        return;
+    }
+
+    constexpr int TS = T::BN + 1;
+    static_assert(T::BM * TS * 4 <= T::RING_BYTES, "the output tile is staged in the ring");
+    float* Tl = smem;  // [BM][BN + 1]
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);
+            Tl[row * TS + wn * 32 + l31] = fmaf(acc[tm][0][r], inv, bias[tm][r]);
+        }
+    if (SP_TRACE_ON(trace)) tr.t[10] = __builtin_readcyclecounter();   // last fold + bias + tile written to LDS
+    __syncthreads();
+    if (SP_TRACE_ON(trace)) tr.t[11] = __builtin_readcyclecounter();
+    // the tile leaves through LDS as 16-byte stores: 16 lanes cover one 256-byte row segment
+#pragma unroll
+    for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
+        const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
+        const float* t = Tl + row * TS + c4;
+        vf4 v = {t[0], t[1], t[2], t[3]};
+        if constexpr (ABL & 16) {   // timing only: no global stores of the tile
+            if (v[0] == 123.456f) U[0] = v[1];
+        } else {
+            *reinterpret_cast<vf4*>(U + (size_t)(rt * T::BM + row) * ld + c0 + c4) = v;
+        }
+    }
+    if (SP_TRACE_ON(trace)) tr.t[12] = __builtin_readcyclecounter();   // tile stores issued
+    {   // per-row (sum, pivot-shifted centred sum of squares) of the real columns of each 64-column tile (mlp0_kernel's form)
+        constexpr int LPR = T::THREADS / T::BM;    // lanes per row
+        constexpr int LPS = LPR / TPW;             // lanes per (row, 64-column tile)
+        constexpr int CPL = MLP0_BN / LPS;         // columns per lane
+        static_assert(LPS >= 1, "at least one lane per row and 64-column tile");
+        const int row = tid / LPR, q = tid % LPR, sub = q / LPS, part = q % LPS;
+        const int valid = min(max(ts.valid - sub * MLP0_BN, 0), MLP0_BN);
+        const float pivot = Tl[row * TS + sub * MLP0_BN];
+        const float* trow = Tl + row * TS + sub * MLP0_BN + part * CPL;
+        // the LPR lanes of a row sit CPL columns apart (a multiple of 32 banks with CPL = 32): each starts its walk 32 / LPR columns
+        // further into its range, so that the lanes of a wave (rows one bank apart, TS odd) cover the 32 banks exactly once per read
+        constexpr int SKEW = (CPL % 32 == 0 && 32 % LPR == 0) ? 32 / LPR : 0;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m0 = 0; m0 < CPL; ++m0) {
+            const int m = (m0 + q * SKEW) % CPL;
+            const float t = trow[m];
+            const float d = (part * CPL + m < valid) ? t - pivot : 0.f;
+            s1 += d;
+            s2 += d * d;
+        }
+#pragma unroll
+        for (int o = 1; o < LPS; o <<= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        if (part == 0) {
+            const float nv = (float)valid;
+            const size_t t64 = (size_t)ct * TPW + sub;
+            statpart[(t64 * 2 + 0) * 512 + rt * T::BM + row] = nv * pivot + s1;                       // sum
+            statpart[(t64 * 2 + 1) * 512 + rt * T::BM + row] = nv > 0.f ? s2 - s1 * s1 / nv : 0.f;    // M2
+        }
+    }
+    if (SP_TRACE_ON(trace) && lane == 0) {   // 24 x u64 per wave: [hw_id, xcc_id, t_entry, t[0..8], t_end, rt, ct, wave, t[9..12], wall clock at entry / exit]
+        unsigned long long* r = trace + ((size_t)blockIdx.x * T::WAVES + wave) * 24;
+        r[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        r[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        r[2] = t_entry;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) r[3 + k] = tr.t[k];
+        r[12] = __builtin_readcyclecounter();
+        r[13] = rt; r[14] = ct; r[15] = wave;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[16 + k] = tr.t[9 + k];
+        r[20] = w_entry; r[21] = wall_clock64();
+    }
+}
+
+// =====================================================================================================
+// K6  mlp.3:  Z = (Z + b3) + W3 relu((u - mean) * rstd)   (mlp3_kernel of the fp32 path).  The InstanceNorm statistics of the
+//     tile's segment sit in an LDS table (mean, rstd x activation pre-scale) and are applied to the raw B values in registers.
+// =====================================================================================================
+template <int MODE>
+using Mlp3SpTile = SpTile<128, 2, 2, 3, MODE>;   // 128 x 64 on 4 waves (252 workgroups at the headline shape)
+
+struct InstNormBx {
+    static constexpr bool ON = true;
+    const float2* tab;   // LDS [512]: (mean, rstd * activation pre-scale)
+    __device__ __forceinline__ void fetch(int k, float2 (&x)[8]) const {
+        const vf4* p = reinterpret_cast<const vf4*>(tab + k);   // k is a multiple of 8: 64-byte aligned
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const vf4 t = p[q];
+            x[2 * q] = make_float2(t[0], t[1]);
+            x[2 * q + 1] = make_float2(t[2], t[3]);
+        }
+    }
+    __device__ __forceinline__ float apply(float v, float2 ms) const { return fmaxf((v - ms.x) * ms.y, 0.f); }
+};
+
+template <class T>
+__global__ __launch_bounds__(T::THREADS, 2) void mlp3_sp_kernel(const float* __restrict__ sc, const float* __restrict__ b3,
+                                                              const unsigned short* __restrict__ P0, const unsigned short* __restrict__ P1,
+                                                              const unsigned short* __restrict__ P2, const float* __restrict__ U,
+                                                              const float* __restrict__ stats, float* __restrict__ Z, ColLayout L) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    float* smem = reinterpret_cast<float*>(smem_c);
+    if constexpr (T::F16) fp16_saturate_mode();
+    int rt, ct;
+    constexpr int MT = 256 / T::BM;
+    constexpr int TPW = T::BN / 64;
+    if (!xcd_tile_map(MT, active_tiles(L) / TPW, rt, ct)) return;
+    ct = global_tile(L, ct * TPW) / TPW;
+    const int c0 = ct * T::BN, ld = L.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    const TileSeg ts = tile_seg(L, c0, T::BN);
+    const float sA = T::F16 ? sc[2] : 1.f;
+    const float scale = sA * T::ACT_SCALE, inv = 1.f / scale;
+    // statistics table behind the ring
+    float2* tab = reinterpret_cast<float2*>(smem_c + T::RING_BYTES);
+    {
+        const float* mean = stats + ((size_t)ts.seg * 2 + 0) * 512;
+        const float* rstd = stats + ((size_t)ts.seg * 2 + 1) * 512;
+        for (int c = tid; c < 512; c += T::THREADS) tab[c] = make_float2(mean[c], rstd[c] * T::ACT_SCALE);
+    }
+    // start from (residual + bias) x the accumulator scale (exact: a power of two)
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rt * T::BM + (wm * T::TM + tm) * 32 + mfma_row(r, half);
+            acc[tm][0][r] = (Z[(size_t)row * ld + c0 + wn * 32 + l31] + b3[row]) * scale;
+        }
+    const size_t ro = (size_t)rt * T::BM * BK;
+    auto apl = [&](int kt, int pl) { return (pl == 0 ? P0 : pl == 1 ? P1 : P2) + ro + (size_t)kt * 256 * BK; };
+    auto bsl = [&](int kt) { return U + (size_t)kt * BK * ld + c0; };
+    SpPlainHooks<false> hooks;
+    InstNormBx bx;
+    bx.tab = tab;
+    gemm_mainloop_sp<T, 512 / BK>(reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, bx);
+    store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [inv](int, float v) { return v * inv; });
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------------
+struct PlaneSet {
+    const unsigned short *p0, *p1, *p2;
+};
+static PlaneSet planes(const unsigned short* wb, int prec, size_t hi, size_t lo, size_t lo2, size_t h16, size_t l16) {
+    if (prec >= 3) return {wb + h16, wb + l16, wb + l16};
+    return {wb + hi, wb + lo, wb + lo2};
+}
+
+template <int MODE>
+static void launch_qkv_sp_t(const float* sc, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    using T = QkvSpTile<MODE>;
+    allow_big_lds_sp<qkv_kv_sp_kernel<T>>();
+    const PlaneSet p = planes(wb, MODE, AttnWB::QKV_HI, AttnWB::QKV_LO, AttnWB::QKV_LO2, AttnWB::QKV_H16, AttnWB::QKV_L16);
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s, sc,
+                   bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
+}
+void launch_qkv_kv_sp(const float* sc, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    switch (w.prec) {
+        case 1: launch_qkv_sp_t<1>(sc, bqkv, wb, w, s, hk); break;
+        case 2: launch_qkv_sp_t<2>(sc, bqkv, wb, w, s, hk); break;
+        case 3: launch_qkv_sp_t<3>(sc, bqkv, wb, w, s, hk); break;
+        default: launch_qkv_sp_t<4>(sc, bqkv, wb, w, s, hk); break;
+    }
+}
+
+template <class T, int ABL = 0, int SCHED = 0>
+static void launch_mlp0_sp_t(const float* sc, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    allow_big_lds_sp<mlp0_sp_kernel<T, ABL, SCHED>>();
+    const PlaneSet p = planes(wb, T::MODE, AttnWB::W0_HI, AttnWB::W0_LO, AttnWB::W0_LO2, AttnWB::W0_H16, AttnWB::W0_L16);
+    const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_sp_kernel<T, ABL, SCHED>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 1024, s, sc, b0,
+                   p.p0, p.p1, p.p2, w.Z, w.Q, w.Mpl, w.ksumT, w.zsc, w.U, w.statpart, w.L, g_trace);
+}
+template <int MODE>
+static void launch_mlp0_sp_m(const float* sc, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    // the 128-column tile (8 waves, one workgroup per CU) moves two thirds of the operand bytes per product through L2: taken when
+    // its 4 x tiles workgroups make ONE round of the 256 CUs and fill at least three quarters of it (the headline shape: 252); with
+    // fewer the 64-column tile (4 waves, two workgroups per CU, twice as many) fills the chip better, with more than one round its
+    // co-resident pairs overlap one workgroup's store tail with the other's loop (fp16x4, 8 frames per step: 179 vs 188 us per launch)
+    static const int wide_min = tuning_knob("SP_MLP0_WIDE_MIN", 48), wide_max = tuning_knob("SP_MLP0_WIDE_MAX", 64);
+#ifdef GATSSPG_TUNING
+    if constexpr (MODE == 4) {   // timing-only ablations of the main loop (wrong results)
+        static const int abl = tuning_knob("SP_ABL", 0);
+        switch (abl) {
+            case 1: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 1>(sc, b0, wb, w, s, hk);     // no DMA after the prologue
+            case 2: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 2>(sc, b0, wb, w, s, hk);     // no MFMAs
+            case 4: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 4>(sc, b0, wb, w, s, hk);     // no split VALU
+            case 8: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 8>(sc, b0, wb, w, s, hk);     // no fragment reads
+            case 14: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 14>(sc, b0, wb, w, s, hk);   // DMA + barriers only
+            case 13: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 13>(sc, b0, wb, w, s, hk);   // MFMAs + barriers only
+            case 15: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 15>(sc, b0, wb, w, s, hk);   // barriers only (+ prologue, epilogue)
+            case 9: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 9>(sc, b0, wb, w, s, hk);     // no DMA, no reads: MFMAs + split
+            case 31: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 31>(sc, b0, wb, w, s, hk);   // skeleton without the tile's global stores
+            case 63: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 63>(sc, b0, wb, w, s, hk);   // skeleton without any epilogue
+            case 16: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 16>(sc, b0, wb, w, s, hk);   // full loop, no global stores of the tile
+            case 48: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 48>(sc, b0, wb, w, s, hk);   // full loop, no epilogue
+            case 100: return launch_mlp0_sp_t<Mlp0SpTileT<MODE>, 0>(sc, b0, wb, w, s, hk);   // (not an ablation) the one-wave-per-SIMD tile
+            case 101: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 1>(sc, b0, wb, w, s, hk);   // (not an ablation) the ping-pong schedule
+            case 102: return launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 1>(sc, b0, wb, w, s, hk);   // ping-pong on the 4-wave tile (groups on different SIMDs)
+            default: break;
+        }
+    }
+#endif
+    if (active_tiles(w.L) / 2 >= wide_min && active_tiles(w.L) / 2 <= wide_max) launch_mlp0_sp_t<Mlp0SpTileW<MODE>>(sc, b0, wb, w, s, hk);
+    else launch_mlp0_sp_t<Mlp0SpTileN<MODE>>(sc, b0, wb, w, s, hk);
+}
+void launch_mlp0_sp(const float* sc, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    switch (w.prec) {
+        case 1: launch_mlp0_sp_m<1>(sc, b0, wb, w, s, hk); break;
+        case 2: launch_mlp0_sp_m<2>(sc, b0, wb, w, s, hk); break;
+        case 3: launch_mlp0_sp_m<3>(sc, b0, wb, w, s, hk); break;
+        default: launch_mlp0_sp_m<4>(sc, b0, wb, w, s, hk); break;
+    }
+}
+
+template <int MODE>
+static void launch_mlp3_sp_t(const float* sc, const float* b3, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    using T = Mlp3SpTile<MODE>;
+    allow_big_lds_sp<mlp3_sp_kernel<T>>();
+    const PlaneSet p = planes(wb, MODE, AttnWB::W3_HI, AttnWB::W3_LO, AttnWB::W3_LO2, AttnWB::W3_H16, AttnWB::W3_L16);
+    const int NT = active_tiles(w.L) / (T::BN / 64);
+    GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc, b3,
+                   p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
+}
+void launch_mlp3_sp(const float* sc, const float* b3, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    switch (w.prec) {
+        case 1: launch_mlp3_sp_t<1>(sc, b3, wb, w, s, hk); break;
+        case 2: launch_mlp3_sp_t<2>(sc, b3, wb, w, s, hk); break;
+        case 3: launch_mlp3_sp_t<3>(sc, b3, wb, w, s, hk); break;
+        default: launch_mlp3_sp_t<4>(sc, b3, wb, w, s, hk); break;
+    }
+}
+
+}  // namespace gatsspg

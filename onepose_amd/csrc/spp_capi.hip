@@ -153,8 +153,14 @@ int spp_forward_profiled(const float* packed, const float* image, int b, int H, 
     memset(&hk, 0, sizeof(hk));
     hk.kernel_id = kernel_id; hk.occurrence = occurrence;
     hk.start = reinterpret_cast<hipEvent_t>(ev_start); hk.stop = reinterpret_cast<hipEvent_t>(ev_stop);
-    return forward_impl(packed, image, b, H, W, nms_radius, keypoint_threshold, max_keypoints, remove_borders, align_corners,
-                        capacity, keypoints, scores, descriptors, counts, workspace, workspace_bytes, stream, flags, &hk);
+    const int rc = forward_impl(packed, image, b, H, W, nms_radius, keypoint_threshold, max_keypoints, remove_borders, align_corners,
+                                capacity, keypoints, scores, descriptors, counts, workspace, workspace_bytes, stream, flags, &hk);
+    if (rc != 0) return rc;
+    // a kernel id that this configuration never launches (e.g. conv1a under SPP_FLAG_PREC_FP16X4 with even H: it is recomputed inside
+    // conv1b's fused kernel) would leave the events unrecorded: say so instead of returning a bracket around nothing
+    if (hk.seen[kernel_id] <= occurrence)
+        return fail("kernel %d was launched %d times in this configuration, occurrence %d never ran", kernel_id, hk.seen[kernel_id], occurrence);
+    return 0;
 }
 
 }  // extern "C"

@@ -53,6 +53,8 @@ class SuperPointEngine:
         self.lib = _native_spp.load()
         self._packed = None
         self._packed_key = None
+        self._packed_event = None      # recorded on the packing stream right after spp_pack_weights
+        self._packed_stream = None
         self._ws = {}
 
     def _params(self):
@@ -63,7 +65,12 @@ class SuperPointEngine:
         ws, bs = self._params()
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in ws + bs)
         if self._packed is not None and key == self._packed_key:
+            cur = torch.cuda.current_stream(device)
+            if cur.cuda_stream != self._packed_stream:     # another stream: order its reads behind the pack / split kernels
+                cur.wait_event(self._packed_event)
             return self._packed
+        if self._packed is not None:
+            torch.cuda.synchronize(self._packed.device)    # re-pack: nobody may still be reading the blob that is dropped below
         for p in ws + bs:
             if not p.is_cuda:
                 raise RuntimeError(f"onepose_amd.SuperPoint runs only on a ROCm GPU (a parameter is on {p.device}); "
@@ -76,6 +83,9 @@ class SuperPointEngine:
         packed = torch.empty(self.lib.spp_packed_weights_bytes() // 4, device=device, dtype=torch.float32)
         with torch.cuda.device(device):
             _native_spp.check(self.lib.spp_pack_weights(ctypes.byref(raw), packed.data_ptr(), _stream(device)), "spp_pack_weights")
+            self._packed_event = torch.cuda.Event()
+            self._packed_event.record(torch.cuda.current_stream(device))
+            self._packed_stream = torch.cuda.current_stream(device).cuda_stream
         # keep_* may be released here: the caching allocator is stream-ordered and the packing kernels were
         # enqueued on this stream
         self._packed, self._packed_key = packed, key

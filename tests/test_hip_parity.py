@@ -623,13 +623,15 @@ def test_instance_norm_is_robust_to_large_channel_means():
 def test_fp16_terms_saturate_instead_of_overflowing(precision):
     """Operands beyond the fp16 range (state values of +-3e5 and 1e30 here: descriptors scaled up before an attention layer) must
     give finite results in the fp16-split modes: the conversions saturate at +-65504 (MODE.FP16_OVFL), they never produce the
-    infinity that a plain fp16 conversion would turn into NaN.  Up to +-131008 the two terms still represent the operand, so a
-    state scaled to +-1e5 must also stay CLOSE to the fp32 arithmetic (InstanceNorm makes the layer scale-invariant enough)."""
+    infinity that a plain fp16 conversion would turn into NaN.  Activations enter the split multiplied by 2^4 (so that small
+    values keep a normal second term), i.e. the two terms represent an activation exactly up to +-8188 (include/gatsspg.h): a
+    state scaled to components of ~1e3 .. 5e3 must stay CLOSE to the fp32 arithmetic (InstanceNorm makes the layer
+    scale-invariant enough)."""
     sd = synthetic.make_state_dict(0)
     data = synthetic.make_inputs(b=1, n1=200, n2=600, num_leaf=8, seed=91)
     x, y = data["descriptors2d_query"], data["descriptors3d_db"]
     outs = {}
-    for scale in (3e5, 1e30):
+    for scale in (2e4, 3e5, 1e30):
         for prec in ("fp32", precision):
             eng = make_model(sd, HP, prec).engine
             dims = eng.load_state(torch.from_numpy(x * np.float32(scale)).to(dev()), torch.from_numpy(y * np.float32(scale)).to(dev()), 8)
@@ -638,12 +640,79 @@ def test_fp16_terms_saturate_instead_of_overflowing(precision):
             outs[(scale, prec)] = (o2.cpu().numpy(), o3.cpu().numpy())
         o2, o3 = outs[(scale, precision)]
         assert np.isfinite(o2).all() and np.isfinite(o3).all(), f"{precision}: non-finite output for operands of magnitude {scale:g}"
-    # descriptors are unit-norm with components ~0.06: x * 3e5 has components ~2e4 .. 1e5, inside the two-term range
-    r2, r3 = outs[(3e5, "fp32")]
-    o2, o3 = outs[(3e5, precision)]
+    # descriptors are unit-norm with components up to ~0.25: x * 2e4 has components up to ~5e3, inside the two-term range
+    assert float(np.abs(x).max()) * 2e4 < 8188 and float(np.abs(y).max()) * 2e4 < 8188
+    r2, r3 = outs[(2e4, "fp32")]
+    o2, o3 = outs[(2e4, precision)]
     rel = max(float(np.abs(o2 - r2).max() / np.abs(r2).max()), float(np.abs(o3 - r3).max() / np.abs(r3).max()))
-    print(f"{precision}: relative deviation from the fp32 arithmetic at operand magnitude ~1e5: {rel:.2e}")
+    print(f"{precision}: relative deviation from the fp32 arithmetic at operand magnitude ~5e3: {rel:.2e}")
     assert rel < 1e-3
+
+
+def attention_propagation_f64(sd, p, x, s):
+    """AttentionPropagation (GATs_SuperGlue.py:69-128) in float64 numpy: the yardstick that separates an arithmetic's own error
+    from the fp32 noise every fp32 evaluation (the reference's included) has at unusual operand scales."""
+    f = lambda k: sd[f"{p}.{k}"].astype(np.float64)                                  # noqa: E731
+    conv = lambda w, b, t: np.einsum("oc,bcn->bon", w[..., 0], t) + b[None, :, None]   # noqa: E731
+    elu1 = lambda t: np.where(t > 0, t, np.expm1(np.minimum(t, 0))) + 1.0            # noqa: E731
+    x, s = x.astype(np.float64), s.astype(np.float64)
+    b, ns = x.shape[0], s.shape[2]
+    q = conv(f("attn.proj.0.weight"), f("attn.proj.0.bias"), x).reshape(b, 64, 4, -1)
+    k = conv(f("attn.proj.1.weight"), f("attn.proj.1.bias"), s).reshape(b, 64, 4, -1)
+    v = conv(f("attn.proj.2.weight"), f("attn.proj.2.bias"), s).reshape(b, 64, 4, -1)
+    Q, K, V = elu1(q), elu1(k), v / ns
+    KV = np.einsum("bdhm,bqhm->bqdh", K, V)
+    Z = 1.0 / (np.einsum("bdhn,bdh->bhn", Q, K.sum(axis=3)) + 1e-6)
+    msg = (np.einsum("bdhn,bqdh,bhn->bqhn", Q, KV, Z) * ns).reshape(b, 256, -1)
+    msg = conv(f("attn.merge.weight"), f("attn.merge.bias"), msg)
+    u = conv(f("mlp.0.weight"), f("mlp.0.bias"), np.concatenate([x, msg], axis=1))
+    u = (u - u.mean(axis=2, keepdims=True)) / np.sqrt(u.var(axis=2, keepdims=True) + 1e-5)
+    return conv(f("mlp.3.weight"), f("mlp.3.bias"), np.maximum(u, 0.0))
+
+
+def test_f64_yardstick_agrees_with_the_oracle():
+    sd = synthetic.make_state_dict(0)
+    data = synthetic.make_inputs(b=1, n1=90, n2=140, num_leaf=8, seed=11)
+    x, y = data["descriptors2d_query"], data["descriptors3d_db"]
+    for a, b_ in ((x, x), (y, x)):
+        assert maxdiff(attention_propagation_f64(sd, "gnn.layers.2", a, b_), orc.attention_propagation(sd, "gnn.layers.2", a, b_)) < 2e-5
+
+
+@pytest.mark.parametrize("precision", ["fp16x4", "bf16x6", "fp16x3"])
+@pytest.mark.parametrize("wscale,w3scale,xscale", [(1.0, 1.0, 1.0), (0.02, 1.0, 1.0), (1e-3, 1.0, 1.0), (1e-3, 0.02, 1.0), (1.0, 1.0, 0.05),
+                                                   (0.02, 1.0, 0.05), (8.0, 4.0, 4.0)])
+def test_split_modes_are_scale_invariant(precision, wscale, w3scale, xscale):
+    """The round-3 advisor's finding: with unscaled fp16 terms every operand below 2^-3 had a SUBNORMAL second term (2^-25 absolute
+    error = only 2^-15 relative at 1e-3), so 'fp32-class' held on the O(0.05) random-weight fixtures only.  Operands are now
+    pre-scaled by exact powers of two (weights per matrix at pack time, activations by 2^4, the message operator by the source
+    count).  This test runs one attention layer with its projection / merge / mlp.0 matrices scaled to entries of ~1e-3 .. 5e-5
+    (InstanceNorm behind mlp.0 re-amplifies whatever error they make to O(1)), with mlp.3 scaled as well, and with small / large
+    activations.  The yardstick is a float64 evaluation: at such scales fp32 itself is noisy (Q = elu(q) + 1 with q ~ 1e-4 keeps
+    10 bits of q), so the bar is stated against the error of THIS library's fp32 arithmetic on the same inputs: a split mode may
+    be at most 3x as far from the float64 result (fp16x3: 8x) plus 2e-6 of the largest delta entry."""
+    sd = {k: v.copy() for k, v in synthetic.make_state_dict(0).items()}
+    for k in sd:
+        if k.startswith("gnn.layers.1.") and k.endswith("weight"):
+            sd[k] = (sd[k] * np.float32(w3scale if ".mlp.3." in k else wscale)).astype(np.float32)
+    data = synthetic.make_inputs(b=1, n1=150, n2=300, num_leaf=8, seed=11)
+    x = (data["descriptors2d_query"] * np.float32(xscale)).astype(np.float32)
+    y = (data["descriptors3d_db"] * np.float32(xscale)).astype(np.float32)
+    p = "gnn.layers.1"
+    ref = {"2D": x.astype(np.float64) + attention_propagation_f64(sd, p, x, x), "3D": y.astype(np.float64) + attention_propagation_f64(sd, p, y, y)}
+    dmax = {k: float(np.abs(v - (x if k == "2D" else y)).max()) for k, v in ref.items()}
+    errs = {}
+    for prec in ("fp32", precision):
+        eng = make_model(sd, HP, prec).engine
+        dims = eng.load_state(torch.from_numpy(x).to(dev()), torch.from_numpy(y).to(dev()), 8)
+        eng.attn_layer(dims, 0, _native.LAYER_SELF)
+        o2, o3 = eng.store_state(dims)
+        errs[prec] = {"2D": maxdiff(o2.cpu().numpy(), ref["2D"]), "3D": maxdiff(o3.cpu().numpy(), ref["3D"])}
+    factor = {"fp16x3": 8.0}.get(precision, 3.0)
+    for side in ("2D", "3D"):
+        e32, e16 = errs["fp32"][side], errs[precision][side]
+        print(f"{precision} W x{wscale:g} W3 x{w3scale:g} act x{xscale:g} {side}: |err| vs float64: fp32 {e32:.3e}, {precision} {e16:.3e} "
+              f"(max |delta| {dmax[side]:.3e}; relative {e16 / dmax[side]:.2e})")
+        assert e16 <= factor * e32 + 2e-6 * dmax[side]
 
 
 @pytest.mark.parametrize("scale,n1,n2", [(0.005, 130, 1027), (0.002, 200, 520), (0.0124, 64, 96)])

@@ -10,5 +10,5 @@ for knobs in "$@"; do
   env $envs python bench.py --tuning-lib --config $C --kernel $K --steps 60 --warmup 10 --reps 3 --no-side-arithmetics --no-cpu-baseline > $O/ab_$tag.json 2>$O/ab_$tag.err
   python -c "
 import json,sys
-d=json.load(open('$O/ab_$tag.json')); print('[$knobs] kernel_ms', d['roofline']['kernel_ms'], 'pair', d['roofline']['empty_event_pair_ms'], 'latency_ms', d['config']['single_frame_latency_ms'], 'inflight', d['value'], 'flips', d['parity_check']['argmax_flips'])" || tail -3 $O/ab_$tag.err
+d=json.load(open('$O/ab_$tag.json')); print('[$knobs] kernel_ms', d['roofline']['kernel_ms'], 'pair', d['roofline']['empty_event_pair_ms'], 'latency_ms', d['config']['single_frame_latency_ms'], 'inflight', d['value'], 'flips', (d.get('parity_check') or {}).get('argmax_flips'))" || tail -3 $O/ab_$tag.err
 done
