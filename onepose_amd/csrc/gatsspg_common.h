@@ -138,6 +138,7 @@ struct Workspace {
     float *Z, *Q, *MSG, *U, *MD;     // MD aliases Q (Q is dead after the GNN); MSG: scratch of the with_linear_transform GATs path
     float *MDT;                      // query-side normalised descriptors, point-major [b][n1p][256]; aliases MSG
     float *kvpart, *kvfin, *statpart, *stats;
+    int *statcnt;                    // [nseg][8] arrival counters of the fused InstanceNorm statistics (stat_last_block)
     // linear attention folded into mlp.0 (kv_final_kernel -> mlp0_kernel): per TARGET segment t the operator
     // M_t = (W0b Wm)[:, head h] KV_h(source) for the four heads [512][4 x 64], and the source's ksum.
     float *Mop;                      // [b][512][512]: segment 2f at columns 256..511, segment 2f+1 at columns 0..255 of frame f's block
@@ -187,6 +188,7 @@ inline Workspace carve_workspace(void* base, int b, int n1, int n2) {
     w.zsc = (float*)take(sizeof(float) * (size_t)w.nseg);
     w.statpart = (float*)take(sizeof(float) * (size_t)w.nt64 * 2 * 512);
     w.stats = (float*)take(sizeof(float) * (size_t)w.nseg * 2 * 512);
+    w.statcnt = (int*)take(sizeof(int) * (size_t)w.nseg * 8);
     w.rowpart = (float*)take(sizeof(float) * (size_t)b * w.sc_nct * L.n1p);
     w.colpart = (float*)take(sizeof(float) * (size_t)b * w.sc_nrt * L.n2p);
     w.rs = (float*)take(sizeof(float) * (size_t)b * L.n1p);

@@ -178,8 +178,8 @@ constexpr int KVF_BLOCKS = 16 * KVF_RS + 1;     // 16 d-row blocks x row halves 
 __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict__ kvpart, const float* __restrict__ kv_src,
                                                         float* __restrict__ kvfin, const float* __restrict__ W0,
                                                         float* __restrict__ Mop, unsigned short* __restrict__ Mpl,
-                                                        float* __restrict__ ksumT, float* __restrict__ zsc, const float* __restrict__ sc,
-                                                        ColLayout L, int cross, int prec, int abl) {
+                                                        float* __restrict__ ksumT, float* __restrict__ zsc, int* __restrict__ statcnt,
+                                                        const float* __restrict__ sc, ColLayout L, int cross, int prec, int abl) {
     __shared__ float4 red[16][64];
     __shared__ float4 kvs[64];   // this block's final KV^T rows: [4 d][16 float4 of q]
     if (prec >= 3) fp16_saturate_mode();
@@ -247,6 +247,8 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
             if (ksum_block) {
                 *reinterpret_cast<float4*>(ksumT + ((size_t)tseg * H + h) * DH + 4 * el) = tot;   // ksum of the source
                 if (h == 0 && el == 0) zsc[tseg] = prec >= 3 ? __builtin_ldexpf(1.f, mexp) : 1.f;
+                // arrival counters of the target segment's fused InstanceNorm statistics (mlp.0 is enqueued behind this launch)
+                if (h == 0 && el < STATCNT_PER_SEG) statcnt[tseg * STATCNT_PER_SEG + el] = 0;
             }
         }
     }
@@ -344,8 +346,8 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(c
                                                    const float* __restrict__ Z, const float* __restrict__ Qbuf,
                                                    const float* __restrict__ Mop, const unsigned short* __restrict__ Mpl,
                                                    const float* __restrict__ ksumT,
-                                                   float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
-                                                   unsigned long long* trace) {
+                                                   float* __restrict__ U, float* __restrict__ statpart, float* __restrict__ stats,
+                                                   int* __restrict__ statcnt, ColLayout L, unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if constexpr (PREC >= 3) fp16_saturate_mode();
     const unsigned long long t_entry = trace ? wall_clock64() : 0;
@@ -423,14 +425,6 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(c
                 Tl[row * TS + col] = acc[tm][tn][r] + bias[tm][r];
             }
     __syncthreads();
-    // the tile leaves through LDS as 16-byte stores: 16 lanes cover one 256-byte row segment
-#pragma unroll
-    for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
-        const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
-        const float* t = Tl + row * TS + c4;
-        vf4 v = {t[0], t[1], t[2], t[3]};
-        *reinterpret_cast<vf4*>(U + (size_t)(rt * T::BM + row) * ld + c0 + c4) = v;
-    }
     {   // per-row (sum, centred sum of squares) of the real columns of each 64-column tile: THREADS / BM lanes per row,
         // each a fixed contiguous column range, combined by shuffles (fixed order).  One pass, shifted by the first
         // column of the row (a pivot within a few std of the mean), so M2 = sum d^2 - (sum d)^2 / n does not cancel even
@@ -459,10 +453,23 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(c
         if (part == 0) {
             const float nv = (float)valid;
             const size_t t64 = (size_t)ct * TPW + sub;
-            statpart[(t64 * 2 + 0) * 512 + rt * T::BM + row] = nv * pivot + s1;                       // sum
-            statpart[(t64 * 2 + 1) * 512 + rt * T::BM + row] = nv > 0.f ? s2 - s1 * s1 / nv : 0.f;    // M2
+            stat_partial_store(statpart + (t64 * 2 + 0) * 512 + rt * T::BM + row, nv * pivot + s1);                      // sum
+            stat_partial_store(statpart + (t64 * 2 + 1) * 512 + rt * T::BM + row, nv > 0.f ? s2 - s1 * s1 / nv : 0.f);   // M2
         }
     }
+    // the partial stores above go first; the tile's own stores follow them and may still be in flight when the ticket is drawn
+    asm volatile("" ::: "memory");
+    // then the tile leaves through LDS as 16-byte stores: 16 lanes cover one 256-byte row segment
+#pragma unroll
+    for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
+        const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
+        const float* t = Tl + row * TS + c4;
+        vf4 v = {t[0], t[1], t[2], t[3]};
+        *reinterpret_cast<vf4*>(U + (size_t)(rt * T::BM + row) * ld + c0 + c4) = v;
+    }
+    constexpr int TILE_STORES = T::BM * (T::BN / 4) / T::THREADS;   // per thread, behind its partial stores
+    static_assert(T::BM * (T::BN / 4) % T::THREADS == 0, "whole stores per thread");
+    if (statcnt) stat_last_block<T, TILE_STORES>(statpart, stats, statcnt, L, ts, rt, smem);   // (nullptr: tuning builds with the stat_final launch)
     if (trace && tid == 0) {
         unsigned long long* r = trace + (size_t)blockIdx.x * 8;
         r[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -900,6 +907,15 @@ static void launch_qkv_t(const float* Wqkv, const float* bqkv, const unsigned sh
 // on the first form: A/B-timed on one box (profiles/r04_split_loop_ab.txt), mlp0 bf16x3 25.0 (first form) vs 25.2 us, 1866 vs 1842
 // frames/s in flight; bf16x6 34.4 vs 40.9 us, 1397 vs 1285 -- the three-plane stage makes the DMA loop 1.5x the LDS traffic.  Tuning
 // builds switch them with GATSSPG_SPLIT_LOOP_BF16X3 / _BF16X6 = 1.
+bool stat_fused() {
+    // measured (profiles/r04_stat_fused_ab.txt, one box, three alternations): the fused form makes mlp0 5.3 us longer (partial-store
+    // acknowledgement -> ticket atomic -> agent-scope loads of the partials: three dependent round trips through the memory side for
+    // the last workgroup) and saves the 4.8 us launch: 1.001 vs 0.983 ms per frame at the headline shape, 1231 vs 1232 frames/s in
+    // flight; +1.7 % in flight at 500 x 2000.  The separate launch stays the default; tuning builds: GATSSPG_STAT_FUSED=1.
+    static const int f = tuning_knob("STAT_FUSED", 0);
+    return f != 0;
+}
+
 bool split_loop_glds(int prec) {
     static const int b3 = tuning_knob("SPLIT_LOOP_BF16X3", 0), b6 = tuning_knob("SPLIT_LOOP_BF16X6", 0);
     return prec >= 3 || (prec == 1 && b3 != 0) || (prec == 2 && b6 != 0);
@@ -922,7 +938,7 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* w
 void launch_kv_final(const float* W0, const Workspace& w, int cross, const float* kv_src, hipStream_t s, ProfileHook* hk) {
     static const int abl = tuning_knob("KVF_ABL", 0);   // tuning builds: timing-only ablations of the operator phase
     GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3(KVF_BLOCKS, w.nseg * H), dim3(1024), 0, s, w.kvpart, kv_src, w.kvfin,
-                   W0, w.Mop, w.Mpl, w.ksumT, w.zsc, W0 - AttnW::W0 + AttnW::SC, w.L, cross, w.prec, abl);
+                   W0, w.Mop, w.Mpl, w.ksumT, w.zsc, w.statcnt, W0 - AttnW::W0 + AttnW::SC, w.L, cross, w.prec, abl);
 }
 
 template <class T, int ABL, int PREC>
@@ -934,7 +950,7 @@ static void launch_mlp0_t(const float* W0, const float* b0, const unsigned short
                    (smem_bytes<T, PREC>() + sizeof(float) * AttnFoldHooks::ZP_FLOATS), s, W0, b0,
                    wb ? wb + (PREC >= 3 ? AttnWB::W0_H16 : AttnWB::W0_HI) : nullptr, wb ? wb + (PREC >= 3 ? AttnWB::W0_L16 : AttnWB::W0_LO) : nullptr,
                    wb ? wb + AttnWB::W0_LO2 : nullptr, w.Z, w.Q, w.Mop, w.Mpl, w.ksumT, w.U,
-                   w.statpart, w.L, g_trace);
+                   w.statpart, w.stats, stat_fused() ? w.statcnt : nullptr, w.L, g_trace);
 }
 template <class T, int ABL, int PREC>
 static void launch_mlp3_t(const float* W3, const float* b3, const unsigned short* wb, const Workspace& w, hipStream_t s,
@@ -971,7 +987,9 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else if (t0 == 16) launch_mlp0_t<Mlp0TileW8, 6, 0>(W0, b0, wb, w, s, hk);   // every load L1-hot
 #endif
     else launch_mlp0_t<Mlp0TileW8, 0, 0>(W0, b0, wb, w, s, hk);
-    GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
+    // (the InstanceNorm statistics are finished inside the mlp.0 launch by its last workgroups: stat_last_block; tuning builds keep the
+    //  separate reducer launch for A/B runs, GATSSPG_STAT_FUSED=0)
+    if (!stat_fused()) GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
     if (sp) launch_mlp3_sp(sc, b3, wb, w, s, hk);
     else if (small3 && t3 == 1) launch_mlp3_t<Mlp3TileS, 0, 0>(W3, b3, wb, w, s, hk);
     else if (w.prec == 1 && t3 == 0) launch_mlp3_t<Mlp3Tile, 0, 1>(W3, b3, wb, w, s, hk);

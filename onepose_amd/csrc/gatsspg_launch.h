@@ -57,6 +57,8 @@ void launch_mlp0_sp(const float* sc, const float* b0, const unsigned short* pack
 void launch_mlp3_sp(const float* sc, const float* b3, const unsigned short* packedb, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 // true if the split-precision launch goes to the kernels above (fp16 modes: always; bf16 modes: unless a tuning build says otherwise)
 bool split_loop_glds(int prec);
+// true: the InstanceNorm statistics are finished inside the mlp.0 launch (no stat_final launch); false only in tuning builds
+bool stat_fused();
 void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 // shifted = 0: E = exp(S) into conf + row/col sum partials (|S| <= 80); 1: raw scores S into conf (max-subtracting path)
 void launch_score_exp(const Workspace& w, float* conf, float scale, int shifted, hipStream_t s, ProfileHook* hk = nullptr);

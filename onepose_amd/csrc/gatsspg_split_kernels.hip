@@ -215,8 +215,8 @@ __global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : 2)) void mlp0_sp_kern
                                                               const unsigned short* __restrict__ P2, const float* __restrict__ Z,
                                                               const float* __restrict__ Qbuf, const unsigned short* __restrict__ Mpl,
                                                               const float* __restrict__ ksumT, const float* __restrict__ zsc,
-                                                              float* __restrict__ U, float* __restrict__ statpart, ColLayout L,
-                                                              unsigned long long* trace) {
+                                                              float* __restrict__ U, float* __restrict__ statpart, float* __restrict__ stats,
+                                                              int* __restrict__ statcnt, ColLayout L, unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     float* smem = reinterpret_cast<float*>(smem_c);
     if constexpr (T::F16) fp16_saturate_mode();
@@ -272,19 +272,6 @@ __global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : 2)) void mlp0_sp_kern
     if (SP_TRACE_ON(trace)) tr.t[10] = __builtin_readcyclecounter();   // last fold + bias + tile written to LDS
     __syncthreads();
     if (SP_TRACE_ON(trace)) tr.t[11] = __builtin_readcyclecounter();
-    // the tile leaves through LDS as 16-byte stores: 16 lanes cover one 256-byte row segment
-#pragma unroll
-    for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
-        const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
-        const float* t = Tl + row * TS + c4;
-        vf4 v = {t[0], t[1], t[2], t[3]};
-        if constexpr (ABL & 16) {   // timing only: no global stores of the tile
-            if (v[0] == 123.456f) U[0] = v[1];
-        } else {
-            *reinterpret_cast<vf4*>(U + (size_t)(rt * T::BM + row) * ld + c0 + c4) = v;
-        }
-    }
-    if (SP_TRACE_ON(trace)) tr.t[12] = __builtin_readcyclecounter();   // tile stores issued
     {   // per-row (sum, pivot-shifted centred sum of squares) of the real columns of each 64-column tile (mlp0_kernel's form)
         constexpr int LPR = T::THREADS / T::BM;    // lanes per row
         constexpr int LPS = LPR / TPW;             // lanes per (row, 64-column tile)
@@ -314,10 +301,28 @@ __global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : 2)) void mlp0_sp_kern
         if (part == 0) {
             const float nv = (float)valid;
             const size_t t64 = (size_t)ct * TPW + sub;
-            statpart[(t64 * 2 + 0) * 512 + rt * T::BM + row] = nv * pivot + s1;                       // sum
-            statpart[(t64 * 2 + 1) * 512 + rt * T::BM + row] = nv > 0.f ? s2 - s1 * s1 / nv : 0.f;    // M2
+            stat_partial_store(statpart + (t64 * 2 + 0) * 512 + rt * T::BM + row, nv * pivot + s1);                      // sum
+            stat_partial_store(statpart + (t64 * 2 + 1) * 512 + rt * T::BM + row, nv > 0.f ? s2 - s1 * s1 / nv : 0.f);   // M2
         }
     }
+    // the partial stores above go first; the tile's own stores follow them and may still be in flight when the ticket is drawn
+    asm volatile("" ::: "memory");
+    // then the tile leaves through LDS as 16-byte stores: 16 lanes cover one 256-byte row segment
+#pragma unroll
+    for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
+        const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
+        const float* t = Tl + row * TS + c4;
+        vf4 v = {t[0], t[1], t[2], t[3]};
+        if constexpr (ABL & 16) {   // timing only: no global stores of the tile
+            if (v[0] == 123.456f) U[0] = v[1];
+        } else {
+            *reinterpret_cast<vf4*>(U + (size_t)(rt * T::BM + row) * ld + c0 + c4) = v;
+        }
+    }
+    if (SP_TRACE_ON(trace)) tr.t[12] = __builtin_readcyclecounter();   // tile stores issued
+    constexpr int TILE_STORES = T::BM * (T::BN / 4) / T::THREADS;   // per thread, behind its partial stores
+    static_assert(T::BM * (T::BN / 4) % T::THREADS == 0, "whole stores per thread");
+    if (statcnt) stat_last_block<T, TILE_STORES>(statpart, stats, statcnt, L, ts, rt, smem);   // (nullptr: tuning builds with the stat_final launch)
     if (SP_TRACE_ON(trace) && lane == 0) {   // 24 x u64 per wave: [hw_id, xcc_id, t_entry, t[0..8], t_end, rt, ct, wave, t[9..12], wall clock at entry / exit]
         unsigned long long* r = trace + ((size_t)blockIdx.x * T::WAVES + wave) * 24;
         r[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -434,7 +439,7 @@ static void launch_mlp0_sp_t(const float* sc, const float* b0, const unsigned sh
     const PlaneSet p = planes(wb, T::MODE, AttnWB::W0_HI, AttnWB::W0_LO, AttnWB::W0_LO2, AttnWB::W0_H16, AttnWB::W0_L16);
     const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
     GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_sp_kernel<T, ABL, SCHED>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 1024, s, sc, b0,
-                   p.p0, p.p1, p.p2, w.Z, w.Q, w.Mpl, w.ksumT, w.zsc, w.U, w.statpart, w.L, g_trace);
+                   p.p0, p.p1, p.p2, w.Z, w.Q, w.Mpl, w.ksumT, w.zsc, w.U, w.statpart, w.stats, stat_fused() ? w.statcnt : nullptr, w.L, g_trace);
 }
 template <int MODE>
 static void launch_mlp0_sp_m(const float* sc, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {

@@ -889,6 +889,86 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// InstanceNorm statistics fused into the mlp.0 launch (replaces the stat_final_kernel launch between mlp.0 and mlp.3): the LAST
+// workgroup of a (segment, row tile) to finish turns the per-tile partials of its rows into mean / rstd.
+//   * every workgroup leaves its partials with write-through (agent-scope) stores, waits for them (vmcnt(0) + barrier) and draws a
+//     ticket from the (segment, row tile) counter with one relaxed agent-scope atomic -- no L2 write-back fence (guide G16, sc1 form);
+//   * the workgroup that draws the last ticket reads ALL partials of its rows with agent-scope loads and merges them exactly like
+//     stat_final_kernel did (Chan's formula in double precision, tile ranges summed in tile order, ranges combined in range order):
+//     the result does not depend on WHICH workgroup is last nor on the order of arrival -- run-to-run bit-identical;
+//   * the counters are zeroed by kv_final_kernel (always enqueued before mlp.0 on the same segments) and reset by the reducer.
+// smem: 2 * THREADS doubles + one int, free at the call.  stats: [seg][2][512] (mean, 1 / sqrt(var + 1e-5)), GATs_SuperGlue.py:126.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int STATCNT_PER_SEG = 8;   // row tiles of mlp.0 per segment (512 / 64 at most)
+__device__ __forceinline__ void stat_partial_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// PENDING: vector-memory instructions this thread issued AFTER its partial stores (the tile's own stores), which may stay in flight
+template <class T, int PENDING>
+__device__ __forceinline__ void stat_last_block(const float* statpart, float* stats, int* cnt, const ColLayout& L, const TileSeg& ts, int rt,
+                                                void* smem_v) {
+    constexpr int BM = T::BM, PARTS = T::THREADS / BM;
+    static_assert(T::THREADS % BM == 0 && 512 / BM <= STATCNT_PER_SEG, "row tile / counter layout");
+    double* red = reinterpret_cast<double*>(smem_v);   // [2][PARTS][BM]
+    int* flag = reinterpret_cast<int*>(red + 2 * PARTS * BM);
+    const int tid = threadIdx.x;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING) : "memory");   // this wave's partial stores (and everything before them) have been acknowledged
+    __syncthreads();                                                  // ... every wave's; nobody still uses the staged tile in LDS
+    if (tid == 0) {
+        const int nwg = (ts.side ? L.n2p : L.n1p) / T::BN;
+        const int old = __hip_atomic_fetch_add(cnt + ts.seg * STATCNT_PER_SEG + rt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = old == nwg - 1;
+    }
+    __syncthreads();
+    if (!*flag) return;   // block-uniform
+    const int row = tid % BM, part = tid / BM;
+    const int t0 = (ts.frame * L.np + (ts.side ? L.n1p : 0)) / MLP0_BN;
+    const int nt = (ts.side ? L.n2p : L.n1p) / MLP0_BN;
+    const int n = ts.side ? L.n2 : L.n1;
+    const int per = (nt + PARTS - 1) / PARTS;
+    const int tb = part * per, te = min(nt, tb + per);
+    const int ch = rt * BM + row;
+    double S = 0.0, QP = 0.0;
+    constexpr int CH = 32;   // tiles per round trip: this workgroup is the last one running in its group, so latency is all that counts
+    for (int tt = tb; tt < te; tt += CH) {   // 2 x 32 loads in flight at a time on clamped addresses
+        float xs[CH], xm[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const size_t tile = (size_t)(t0 + min(tt + u, nt - 1));
+            xs[u] = __hip_atomic_load(statpart + (tile * 2 + 0) * 512 + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xm[u] = __hip_atomic_load(statpart + (tile * 2 + 1) * 512 + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int t = tt + u;
+            const int nv = min(MLP0_BN, n - t * MLP0_BN);   // real columns of tile t of this segment (<= 0: pad-only tile)
+            if (t < te && nv > 0) {
+                const double st = (double)xs[u], mt = (double)xm[u];
+                const double inv = nv == MLP0_BN ? 1.0 / MLP0_BN : 1.0 / nv;
+                S += st;
+                QP += mt + st * st * inv;
+            }
+        }
+    }
+    red[(0 * PARTS + part) * BM + row] = S;
+    red[(1 * PARTS + part) * BM + row] = QP;
+    __syncthreads();
+    if (part == 0) {
+        S = red[row];
+        QP = red[PARTS * BM + row];
+#pragma unroll
+        for (int p = 1; p < PARTS; ++p) {
+            S += red[p * BM + row];
+            QP += red[(PARTS + p) * BM + row];
+        }
+        const double mean = S / n;
+        double var = (QP - S * mean) / n;
+        if (var < 0.0) var = 0.0;
+        stats[((size_t)ts.seg * 2 + 0) * 512 + ch] = (float)mean;
+        stats[((size_t)ts.seg * 2 + 1) * 512 + ch] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    if (tid == 0) __hip_atomic_store(cnt + ts.seg * STATCNT_PER_SEG + rt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // XCD-aware block -> (row tile, column tile) map (cdna guide T1): workgroup id g is dispatched
 // to XCD g % 8; give each XCD whole column tiles and walk that tile's row tiles back to back so
 // the B panel [K x BN] is fetched into one XCD's L2 once and re-used by all M/BM row tiles.
