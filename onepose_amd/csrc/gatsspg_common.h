@@ -137,6 +137,7 @@ struct Workspace {
     int cf_nst, cf_nch;   // conf-finalize strips / chunks per frame
     float *Z, *Q, *MSG, *U, *MD;     // MD aliases Q (Q is dead after the GNN); MSG: scratch of the with_linear_transform GATs path
     float *MDT;                      // query-side normalised descriptors, point-major [b][n1p][256]; aliases MSG
+    unsigned short *MDTp;            // their 16-bit planes for the split score contraction (bf16x6 / fp16x4): [3][8 slabs][b * n1p][32], slab-major
     float *kvpart, *kvfin, *statpart, *stats;
     int *statcnt;                    // [nseg][8] arrival counters of the fused InstanceNorm statistics (stat_last_block)
     // linear attention folded into mlp.0 (kv_final_kernel -> mlp0_kernel): per TARGET segment t the operator
@@ -180,6 +181,7 @@ inline Workspace carve_workspace(void* base, int b, int n1, int n2) {
     w.U = (float*)take(sizeof(float) * 2 * D * ld);
     w.MD = w.Q;
     w.MDT = w.MSG;   // b * n1p * 256 floats <= 256 * ld
+    w.MDTp = (unsigned short*)take(sizeof(unsigned short) * 3 * (size_t)b * L.n1p * D);
     w.kvpart = (float*)take(sizeof(float) * (size_t)w.nt64 * H * KVP);
     w.kvfin = (float*)take(sizeof(float) * (size_t)w.nseg * H * KVP);
     w.Mop = (float*)take(sizeof(float) * (size_t)b * 512 * MOP_LD);

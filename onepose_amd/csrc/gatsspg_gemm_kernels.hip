@@ -618,10 +618,14 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp3_kernel(c
 // =====================================================================================================
 using FinalTile = GemmTile<256, 32, 8, 1, false>;   // 8 waves x one 32x32 tile (4 waves x 64x32 left one wave per SIMD: 15.0 us)
 
+// planes_prec: 0, or the arithmetic (2 bf16x6 / 4 fp16x4) whose 16-bit planes of the query descriptors (MDTp, slab-major over all b * n1p
+// rows; fp16: of 2^SCORE_SPLIT_SCALE_LOG2 x) the split score contraction reads as its A operand
 __global__ __launch_bounds__(FinalTile::THREADS) void final_proj_norm_kernel(const float* __restrict__ Wf, const float* __restrict__ bf,
                                                               const float* __restrict__ Z, float* __restrict__ MD,
-                                                              float* __restrict__ MDT, ColLayout L) {
+                                                              float* __restrict__ MDT, unsigned short* __restrict__ MDTp,
+                                                              int planes_prec, ColLayout L) {
     using T = FinalTile;
+    if (planes_prec >= 3) fp16_saturate_mode();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float npart[T::WM][32];
     const int ct = blockIdx.x;
@@ -676,6 +680,28 @@ __global__ __launch_bounds__(FinalTile::THREADS) void final_proj_norm_kernel(con
         for (int idx = tid; idx < 32 * (D / 4); idx += T::THREADS) {
             const int pt = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
             *reinterpret_cast<vf4*>(dst + (size_t)pt * D + c4) = *reinterpret_cast<const vf4*>(smem + pt * TS + c4);
+        }
+        if (planes_prec) {
+            // (point, slab, quarter) -> 8 consecutive channels -> one 16-byte piece of every plane; element (m, k) of a plane at
+            // ((k / 32) * R + m) * 32 + k % 32, R = b * n1p rows
+            const size_t R = (size_t)L.b * L.n1p;
+            const size_t m0 = (size_t)ts.frame * L.n1p + (c0 - ts.seg_start);
+            const float sc = planes_prec >= 3 ? (float)(1 << SCORE_SPLIT_SCALE_LOG2) : 1.f;
+#pragma unroll
+            for (int idx = tid; idx < 32 * 32; idx += T::THREADS) {
+                const int pt = idx >> 5, slab = (idx >> 2) & 7, q = idx & 3;
+                const float* v = smem + pt * TS + slab * 32 + q * 8;
+                unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (planes_prec >= 3) { fp16_split2(v[2 * e] * sc, v[2 * e + 1] * sc, p0[e], p1[e]); p2[e] = 0; }
+                    else bf16_split3(v[2 * e], v[2 * e + 1], p0[e], p1[e], p2[e]);
+                }
+                unsigned short* d0 = MDTp + ((size_t)slab * R + m0 + pt) * 32 + q * 8;
+                *reinterpret_cast<u32x4*>(d0) = (u32x4){p0[0], p0[1], p0[2], p0[3]};
+                *reinterpret_cast<u32x4*>(d0 + R * D) = (u32x4){p1[0], p1[1], p1[2], p1[3]};
+                if (planes_prec == 2) *reinterpret_cast<u32x4*>(d0 + 2 * R * D) = (u32x4){p2[0], p2[1], p2[2], p2[3]};
+            }
         }
     }
 }
@@ -1005,7 +1031,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
 void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     allow_big_lds<final_proj_norm_kernel>();
     GATSSPG_LAUNCH(hk, KID_FINAL_PROJ, s, final_proj_norm_kernel, dim3(w.L.ld / FinalTile::BN), dim3(FinalTile::THREADS),
-                   (smem_bytes<FinalTile>()), s, Wf, bf, w.Z, w.MD, w.MDT, w.L);
+                   (smem_bytes<FinalTile>()), s, Wf, bf, w.Z, w.MD, w.MDT, w.MDTp, score_on_split_loop(w.prec, 0) ? w.prec : 0, w.L);
 }
 
 static bool score_square() {
@@ -1023,7 +1049,17 @@ static void launch_score_t(const Workspace& w, float* conf, float scale, hipStre
                    (smem_bytes<T>()), s, w.MDT, w.MD, conf, w.rowpart, w.colpart, w.L, scale);
 }
 
+static bool score_square();
+// The fp32-class split modes (bf16x6: operands split exactly; fp16x4: the exact product of 22-bit operands) also run the score
+// contraction on the 16-bit pipe; the three-term modes keep the fp32 MFMA here (their 2^-16 / dropped-term error would sit directly on
+// the logits of the dual softmax).  The max-subtracting path (tiny scale factors) stays fp32 as well.
+bool score_on_split_loop(int prec, int shifted) {
+    static const int on = tuning_knob("SCORE_SPLIT", 1);
+    return on != 0 && !shifted && (prec == 2 || prec == 4) && !score_square();   // (its partial sums are per 64-column tile)
+}
+
 void launch_score_exp(const Workspace& w, float* conf, float scale, int shifted, hipStream_t s, ProfileHook* hk) {
+    if (score_on_split_loop(w.prec, shifted)) return launch_score_exp_sp(w, conf, scale, s, hk);
     const bool sq = score_square();
     if (shifted && sq) launch_score_t<ScoreTileSq, true>(w, conf, scale, s, hk);
     else if (shifted) launch_score_t<ScoreTileW8, true>(w, conf, scale, s, hk);

@@ -55,6 +55,11 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
 void launch_qkv_kv_sp(const float* sc, const float* bqkv, const unsigned short* packedb, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 void launch_mlp0_sp(const float* sc, const float* b0, const unsigned short* packedb, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 void launch_mlp3_sp(const float* sc, const float* b3, const unsigned short* packedb, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+// score contraction + exp on the split loop (fp32-class modes only: bf16x6, fp16x4): A = the 16-bit planes of the query descriptors
+// written by final_proj_norm_kernel (w.MDTp), B = the fp32 3D descriptors.  Same outputs and partial layout as launch_score_exp.
+bool score_on_split_loop(int prec, int shifted);
+void launch_score_exp_sp(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk = nullptr);
+constexpr int SCORE_SPLIT_SCALE_LOG2 = 10;   // unit-norm descriptors (|x| <= 1) are multiplied by 2^10 before the fp16 split
 // true if the split-precision launch goes to the kernels above (fp16 modes: always; bf16 modes: unless a tuning build says otherwise)
 bool split_loop_glds(int prec);
 // true: the InstanceNorm statistics are finished inside the mlp.0 launch (no stat_final launch); false only in tuning builds

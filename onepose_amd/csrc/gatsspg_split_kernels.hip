@@ -405,9 +405,115 @@ __global__ __launch_bounds__(T::THREADS, 2) void mlp3_sp_kernel(const float* __r
     store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [inv](int, float v) { return v * inv; });
 }
 
+// =====================================================================================================
+// K8  score contraction + exp (score_exp_kernel of the fp32 path, GATs_SuperGlue.py:217-218) on the split loop, for the fp32-class
+//     arithmetics only (bf16x6, fp16x4):  E[n][m] = exp( (sum_d A[n][d] B[d][m]) / scale_factor ),  A = the 16-bit planes of the
+//     normalised query descriptors (written by final_proj_norm_kernel: unit-norm rows, fp16 planes of 2^10 x), B = the fp32
+//     normalised 3D descriptors, split in registers with the same 2^10.  Same tile (128 x 64), same partial-sum layout and the same
+//     epilogue as the fp32 kernel: conf_finalize_kernel cannot tell them apart.
+// =====================================================================================================
+template <int MODE>
+using ScoreSpTile = SpTile<SC_BM, 2, 2, 2, MODE, SCORE_SPLIT_SCALE_LOG2>;
+
+template <class T>
+__global__ __launch_bounds__(T::THREADS, 3) void score_exp_sp_kernel(const unsigned short* __restrict__ MDTp, const float* __restrict__ MD,
+                                                                   float* __restrict__ conf, float* __restrict__ rowpart,
+                                                                   float* __restrict__ colpart, ColLayout L, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    float* smem = reinterpret_cast<float*>(smem_c);
+    static_assert(T::BN == SC_BN && T::BM == SC_BM, "partial sums are per 128 x 64 tile");
+    if constexpr (T::F16) fp16_saturate_mode();
+    const int nrt = L.n1p / T::BM, nct = L.n2p / T::BN;   // segments are padded to multiples of 128
+    int rt, ct;
+    const int frame = blockIdx.y;
+    if (!xcd_tile_map(nrt, nct, rt, ct)) return;
+    const int ld = L.ld;
+    const size_t R = (size_t)L.b * L.n1p;
+    const size_t m0 = (size_t)frame * L.n1p + (size_t)rt * T::BM;
+    const float* Bp = MD + (size_t)frame * L.np + L.n1p + ct * T::BN;
+    f32x16 acc[T::TM][T::TN];
+    auto apl = [&](int kt, int pl) { return MDTp + (size_t)pl * R * D + ((size_t)kt * R + m0) * BK; };
+    auto bsl = [&](int kt) { return Bp + (size_t)kt * BK * ld; };
+    SpPlainHooks<true> hooks;
+    SpNoBx nobx;
+    gemm_mainloop_sp<T, D / BK>(reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx);
+    const float inv = T::F16 ? 1.f / (T::ACT_SCALE * T::ACT_SCALE) : 1.f;   // both operands carry the scale
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    constexpr int TS = T::BN + 1;
+    static_assert(T::BM * TS * 4 <= T::RING_BYTES, "the output tile is staged in the ring");
+    float* Tl = smem;  // [128][65]
+    float* cf = conf + (size_t)frame * L.n1 * L.n2;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);
+            const int col = wn * 32 + l31;
+            const int gi = rt * T::BM + row, gj = ct * T::BN + col;
+            const float sc = (acc[tm][0][r] * inv) / scale;
+            Tl[row * TS + col] = (gi < L.n1 && gj < L.n2) ? expf(sc) : 0.f;
+        }
+    __syncthreads();
+    if ((L.n2 & 3) == 0 && (reinterpret_cast<uintptr_t>(cf) & 15) == 0) {
+        for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
+            const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
+            const int gi = rt * T::BM + row, gj = ct * T::BN + c4;
+            if (gi < L.n1 && gj < L.n2) {
+                const float* t = Tl + row * TS + c4;
+                vf4 v = {t[0], t[1], t[2], t[3]};
+                *reinterpret_cast<vf4*>(cf + (size_t)gi * L.n2 + gj) = v;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < T::BM * T::BN; idx += T::THREADS) {
+            const int row = idx / T::BN, col = idx % T::BN;
+            const int gi = rt * T::BM + row, gj = ct * T::BN + col;
+            if (gi < L.n1 && gj < L.n2) cf[(size_t)gi * L.n2 + gj] = Tl[row * TS + col];
+        }
+    }
+    {   // row sums: THREADS / BM lanes per row; column sums: THREADS / BN row groups, one thread per (group, column); fixed order
+        constexpr int LPR = T::THREADS / T::BM, CPL = T::BN / LPR;
+        const int row = tid / LPR, hp = tid % LPR;
+        const float* tr = Tl + row * TS + hp * CPL;
+        float s = 0.f;
+#pragma unroll 8
+        for (int m = 0; m < CPL; ++m) s += tr[m];
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+        if (hp == 0 && rt * T::BM + row < L.n1p) rowpart[((size_t)frame * nct + ct) * L.n1p + rt * T::BM + row] = s;
+        constexpr int NQ = T::THREADS / T::BN, RPQ = T::BM / NQ;
+        const int c = tid % T::BN, qp = tid / T::BN;
+        float t = 0.f;
+#pragma unroll 8
+        for (int m = 0; m < RPQ; ++m) t += Tl[(qp * RPQ + m) * TS + c];
+        __syncthreads();
+        Tl[qp * T::BN + c] = t;
+        __syncthreads();
+        if (tid < T::BN) {
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) tot += Tl[q * T::BN + tid];
+            colpart[((size_t)frame * nrt + rt) * L.n2p + ct * T::BN + tid] = tot;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------------
+template <int MODE>
+static void launch_score_sp_t(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk) {
+    using T = ScoreSpTile<MODE>;
+    allow_big_lds_sp<score_exp_sp_kernel<T>>();
+    GATSSPG_LAUNCH(hk, KID_SCORE_EXP, s, (score_exp_sp_kernel<T>), dim3(xcd_grid(w.L.n1p / T::BM, w.L.n2p / T::BN), w.L.b), dim3(T::THREADS),
+                   (size_t)T::RING_BYTES, s, w.MDTp, w.MD, conf, w.rowpart, w.colpart, w.L, scale);
+}
+void launch_score_exp_sp(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk) {
+    if (w.prec == 2) launch_score_sp_t<2>(w, conf, scale, s, hk);
+    else launch_score_sp_t<4>(w, conf, scale, s, hk);
+}
+
 struct PlaneSet {
     const unsigned short *p0, *p1, *p2;
 };

@@ -62,7 +62,8 @@ __device__ __forceinline__ void wait_dma_barrier_if(int on) {
 constexpr int FP16_ACT_SCALE_LOG2 = 4;   // activations are multiplied by 2^4 before the fp16 split (exact), range +-8188
 
 // MODE = Workspace::prec: 1 bf16x3, 2 bf16x6, 3 fp16x3, 4 fp16x4
-template <int BM_, int WM_, int WN_, int NST_, int MODE_>
+// ASL: log2 of the power of two the B operand (activations) is multiplied by before an fp16 split (ignored by the bf16 modes)
+template <int BM_, int WM_, int WN_, int NST_, int MODE_, int ASL_ = FP16_ACT_SCALE_LOG2>
 struct SpTile {
     static constexpr int BM = BM_, WM = WM_, WN = WN_, NST = NST_, MODE = MODE_;
     static constexpr int TM = BM / WM / 32, TN = 1, BN = 32 * WN;
@@ -77,7 +78,7 @@ struct SpTile {
     static constexpr int NA = A_BYTES / 1024, NB = B_BYTES / 1024;   // 1 KiB DMA pieces (one wave-instruction each) per slab
     static constexpr int G = (NA + NB) / WAVES;                      // pieces per wave per slab
     static constexpr int SMEM_FLOATS = RING_BYTES / 4;               // what an epilogue may re-use after the loop
-    static constexpr float ACT_SCALE = F16 ? (float)(1 << FP16_ACT_SCALE_LOG2) : 1.f;
+    static constexpr float ACT_SCALE = F16 ? (float)(1 << ASL_) : 1.f;
     static_assert(TM >= 1 && BM % (32 * WM) == 0, "wave tile");
     static_assert(BM % 16 == 0 && (NA + NB) % WAVES == 0, "DMA pieces must divide evenly over the waves");
     static_assert(NST == 2 || NST == 3, "two or three stages");
