@@ -91,6 +91,9 @@ def roofline_floors(n1, n2, precision):
     gemm = 8 * (kernel_flops("mlp0", n1, n2) + kernel_flops("mlp3", n1, n2) + 2 * 768 * 256 * n)
     rest = f_alg(n1, n2, NUM_LEAF) - 8 * 21 * n * 256 * 256       # GATs + final_proj + score (+ nothing of the attention layers)
     rest += 8 * 2 * 256 * 64 * n                                  # the KV pass of qkv_kv stays on the fp32 MFMA in every mode
+    if precision in ("bf16x6", "fp16x4"):                         # fp32-class split modes: the score contraction runs on the split loop too
+        gemm += 2 * n1 * n2 * 256
+        rest -= 2 * n1 * n2 * 256
     if nterms:
         mfma_ms = (gemm * nterms / PEAK_BF16_MFMA_TFLOPS + rest / PEAK_F32_MFMA_TFLOPS) / 1e9
     else:
@@ -382,6 +385,8 @@ def main_extractor(args):
                       algorithmic_vs_f32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic("spp_" + kernel + "_fp16x4"))
             if kernel == "conv1b":
                 rf["kernel"] = "conv1ab_pool_f16_kernel (conv1a recomputed + conv1b + ReLU + pool; conv1b's flops credited only)"
+                rf["frac_is"] = ("credited (conv1b) flops x 4 products / dense 16-bit peak: a LOWER bound of the matrix-pipe utilisation -- the "
+                                 "kernel also issues the recomputed conv1a's MFMAs (K = 9 padded to 16: +25 % products), which are not credited")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = spp_cpu_baseline()
         print(json.dumps(out), flush=True)
@@ -890,7 +895,8 @@ def main():
             "config": {"workload": cfg["what"], "name": args.config,
                        "gemm_precision": "f32 MFMA (exact)" if cfg["precision"] == "fp32" else
                        f"split-{cfg['precision'][:4]} MFMA ({cfg['precision']}) in qkv_kv / mlp0 / mlp3 via GATSSPG_FLAG_PREC_{cfg['precision'].upper()}; "
-                       "final_proj, score, GATs fp32",
+                       + ("the score contraction of the dual softmax on the same split arithmetic (fp32-class modes only); final_proj, GATs, "
+                          "the KV pass and every reduction fp32" if cfg["precision"] in ("bf16x6", "fp16x4") else "final_proj, score, GATs fp32"),
                        "n_2d": n1, "n_3d": n2, "num_leaf": NUM_LEAF, "batch": bsz, "steps_per_gpu": K, "frames_per_gpu": K * bsz,
                        "frames_in_flight_per_gpu": S * bsz, "timed_pass_repetitions": R,
                        "timed_pass_seconds": [round(t, 5) for t in reps], "reported": "median repetition",
