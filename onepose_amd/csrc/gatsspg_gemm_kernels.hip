@@ -938,12 +938,11 @@ bool stat_fused() {
     // acknowledgement -> ticket atomic -> agent-scope loads of the partials: three dependent round trips through the memory side for
     // the last workgroup) and saves the 4.8 us launch: 1.001 vs 0.983 ms per frame at the headline shape, 1231 vs 1232 frames/s in
     // flight; +1.7 % in flight at 500 x 2000.  The separate launch stays the default; tuning builds: GATSSPG_STAT_FUSED=1.
-    static const int f = tuning_knob("STAT_FUSED", 0);
-    return f != 0;
+    return tuning_knob("STAT_FUSED", 0) != 0;   // (read per launch: tools/ab_live.py)
 }
 
 bool split_loop_glds(int prec) {
-    static const int b3 = tuning_knob("SPLIT_LOOP_BF16X3", 0), b6 = tuning_knob("SPLIT_LOOP_BF16X6", 0);
+    const int b3 = tuning_knob("SPLIT_LOOP_BF16X3", 0), b6 = tuning_knob("SPLIT_LOOP_BF16X6", 0);   // (read per launch: tools/ab_live.py)
     return prec >= 3 || (prec == 1 && b3 != 0) || (prec == 2 && b6 != 0);
 }
 
@@ -1054,7 +1053,7 @@ static bool score_square();
 // contraction on the 16-bit pipe; the three-term modes keep the fp32 MFMA here (their 2^-16 / dropped-term error would sit directly on
 // the logits of the dual softmax).  The max-subtracting path (tiny scale factors) stays fp32 as well.
 bool score_on_split_loop(int prec, int shifted) {
-    static const int on = tuning_knob("SCORE_SPLIT", 1);
+    const int on = tuning_knob("SCORE_SPLIT", 1);   // (read per launch: tools/ab_live.py)
     return on != 0 && !shifted && (prec == 2 || prec == 4) && !score_square();   // (its partial sums are per 64-column tile)
 }
 

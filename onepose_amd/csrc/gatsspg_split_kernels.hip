@@ -59,7 +59,7 @@ __device__ __forceinline__ void load_bias16(const float* b, int row0, int wm, in
 template <int MODE>
 using QkvSpTile = SpTile<128, 2, 2, 2, MODE>;
 
-template <class T>
+template <class T, int SCHED = 0>
 __global__ __launch_bounds__(T::THREADS, 3) void qkv_kv_sp_kernel(const float* __restrict__ sc, const float* __restrict__ bqkv,
                                                                 const unsigned short* __restrict__ P0, const unsigned short* __restrict__ P1,
                                                                 const unsigned short* __restrict__ P2, const float* __restrict__ Z,
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(T::THREADS, 3) void qkv_kv_sp_kernel(const float* _
     auto bsl = [&](int kt) { return Z + (size_t)kt * BK * ld + c0; };
     SpPlainHooks<true> hooks;
     SpNoBx nobx;
-    gemm_mainloop_sp<T, D / BK>(reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx);
+    gemm_mainloop_sp<T, D / BK, decltype(apl), decltype(bsl), SpPlainHooks<true>, SpNoBx, 0, SCHED>(reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c,
+                                                                                                 apl, bsl, ld, hooks, nobx);
 
     if (rt < 2) {
 #pragma unroll
@@ -207,10 +208,12 @@ using Mlp0SpTileW = SpTile<128, 2, 4, 3, MODE>;   // 128 x 128 on 8 waves: 252 w
 template <int MODE>
 using Mlp0SpTileN = SpTile<128, 2, 2, 3, MODE>;   // 128 x 64 on 4 waves: twice the workgroups (small shapes), two per CU
 template <int MODE>
+using Mlp0SpTileN2 = SpTile<128, 2, 2, 2, MODE>;  // the same on a two-stage ring (49 KiB): three workgroups per CU when the registers allow (<= 168)
+template <int MODE>
 using Mlp0SpTileT = SpTile<128, 1, 4, 3, MODE>;   // 128 x 128 on 4 waves, 128 x 32 per wave (one wave per SIMD, every B value split once)
 
 template <class T, int ABL = 0, int SCHED = 0>
-__global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : 2)) void mlp0_sp_kernel(const float* __restrict__ sc, const float* __restrict__ b0,
+__global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : (T::WAVES == 4 && T::NST == 2) ? 3 : 2)) void mlp0_sp_kernel(const float* __restrict__ sc, const float* __restrict__ b0,
                                                               const unsigned short* __restrict__ P0, const unsigned short* __restrict__ P1,
                                                               const unsigned short* __restrict__ P2, const float* __restrict__ Z,
                                                               const float* __restrict__ Qbuf, const unsigned short* __restrict__ Mpl,
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : 2)) void mlp0_sp_kern
     const TileSeg ts = tile_seg(L, c0, T::BN);
     // ksum of the source segment -> LDS table behind the ring (published by the first barrier of the main loop)
     float* tab = reinterpret_cast<float*>(smem_c + T::RING_BYTES);
-    if (tid < 64) reinterpret_cast<vf4*>(tab)[tid] = ldg4(ksumT + (size_t)ts.seg * H * DH + 4 * tid);
+    // (filled by ONE LDS-DMA piece in front of the first slab requests: no register hop, no wait of its own)
     // requested before the main loop (behind it the two dependent round trips would sit on the critical path: measured 3.9 k cycles of
     // a 39 k-cycle kernel); hipcc parks some of the 32 values in scratch across the loop, which costs two scratch instructions each
     float bias[T::TM][16];
@@ -250,8 +253,11 @@ __global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : 2)) void mlp0_sp_kern
     AttnFoldSp<T::TM> hooks;
     hooks.ks = tab; hooks.zfac = zsc[ts.seg]; hooks.half = half;
     SpNoBx nobx;
-    gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), AttnFoldSp<T::TM>, SpNoBx, ABL, SCHED>(
-        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx, SP_TRACE_ON(trace) ? &tr : nullptr);
+    auto pre = [&]() {
+        if (wave == 0) glds16(ksumT + (size_t)ts.seg * H * DH + 4 * lane, tab);   // [4][64] floats = 1 KiB
+    };
+    gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), AttnFoldSp<T::TM>, SpNoBx, ABL, SCHED, decltype(pre)>(
+        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx, &tr, pre, SP_TRACE_ON(trace));
     if (SP_TRACE_ON(trace)) tr.t[9] = __builtin_readcyclecounter();    // behind the loop's last barrier
     hooks.template fold<3>(reinterpret_cast<f32x16(&)[T::TM]>(acc));
     if constexpr (ABL & 32) {   // timing only: no epilogue at all (one store keeps the accumulators alive)
@@ -259,9 +265,12 @@ __global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : 2)) void mlp0_sp_kern
         return;
     }
 
-    constexpr int TS = T::BN + 1;
+    // staging tile [BM][BN + 4]: the row stride (4 banks) keeps the scalar writes from the MFMA layout, the 16-byte row reads of the
+    // store pass AND (with the walk skew below) the statistics reads free of bank conflicts (the [BN + 1] form of the fp32 kernel costs
+    // a 4-way conflict on every read of the store pass: 12 % of this kernel's LDS cycles in profiles/r04_pmc_fp16x4_sq_lds.txt)
+    constexpr int TS = T::BN + 4;
     static_assert(T::BM * TS * 4 <= T::RING_BYTES, "the output tile is staged in the ring");
-    float* Tl = smem;  // [BM][BN + 1]
+    float* Tl = smem;
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
@@ -281,13 +290,15 @@ __global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : 2)) void mlp0_sp_kern
         const int valid = min(max(ts.valid - sub * MLP0_BN, 0), MLP0_BN);
         const float pivot = Tl[row * TS + sub * MLP0_BN];
         const float* trow = Tl + row * TS + sub * MLP0_BN + part * CPL;
-        // the LPR lanes of a row sit CPL columns apart (a multiple of 32 banks with CPL = 32): each starts its walk 32 / LPR columns
-        // further into its range, so that the lanes of a wave (rows one bank apart, TS odd) cover the 32 banks exactly once per read
-        constexpr int SKEW = (CPL % 32 == 0 && 32 % LPR == 0) ? 32 / LPR : 0;
+        // the LPR lanes of a row start a multiple of 32 banks apart and rows are 4 banks apart: lane (row, q) starts its walk
+        // q + LPR * ((row >> 3) mod (4 / LPR)) columns into its range, so that the 32 lanes of a read (32 / LPR rows) cover the 32 banks once
+        static_assert(TS % 32 == 4, "walk skew of the statistics reads");
+        constexpr bool SKEWED = CPL == 32 && (LPR == 4 || LPR == 2);   // (the one-wave-per-SIMD tuning tile walks 64 columns per lane: unskewed)
+        const int skew = SKEWED ? q + (LPR == 2 ? 2 * ((row >> 3) & 1) : 0) : 0;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int m0 = 0; m0 < CPL; ++m0) {
-            const int m = (m0 + q * SKEW) % CPL;
+            const int m = (m0 + skew) % CPL;
             const float t = trow[m];
             const float d = (part * CPL + m < valid) ? t - pivot : 0.f;
             s1 += d;
@@ -311,8 +322,7 @@ __global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : 2)) void mlp0_sp_kern
 #pragma unroll
     for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
         const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
-        const float* t = Tl + row * TS + c4;
-        vf4 v = {t[0], t[1], t[2], t[3]};
+        const vf4 v = *reinterpret_cast<const vf4*>(Tl + row * TS + c4);
         if constexpr (ABL & 16) {   // timing only: no global stores of the tile
             if (v[0] == 123.456f) U[0] = v[1];
         } else {
@@ -344,24 +354,27 @@ __global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : 2)) void mlp0_sp_kern
 // =====================================================================================================
 template <int MODE>
 using Mlp3SpTile = SpTile<128, 2, 2, 3, MODE>;   // 128 x 64 on 4 waves (252 workgroups at the headline shape)
+template <int MODE>
+using Mlp3SpTile2 = SpTile<128, 2, 2, 2, MODE>;  // two-stage ring (52 KiB with the statistics table): three workgroups per CU
 
 struct InstNormBx {
     static constexpr bool ON = true;
-    const float2* tab;   // LDS [512]: (mean, rstd * activation pre-scale)
+    const float* tab;   // LDS: mean[512] | rstd[512]
     __device__ __forceinline__ void fetch(int k, float2 (&x)[8]) const {
-        const vf4* p = reinterpret_cast<const vf4*>(tab + k);   // k is a multiple of 8: 64-byte aligned
+        const vf4* pm = reinterpret_cast<const vf4*>(tab + k);         // k is a multiple of 8: 32-byte aligned
+        const vf4* pr = reinterpret_cast<const vf4*>(tab + 512 + k);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const vf4 t = p[q];
-            x[2 * q] = make_float2(t[0], t[1]);
-            x[2 * q + 1] = make_float2(t[2], t[3]);
+        for (int q = 0; q < 2; ++q) {
+            const vf4 m = pm[q], r = pr[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[4 * q + e] = make_float2(m[e], r[e]);
         }
     }
     __device__ __forceinline__ float apply(float v, float2 ms) const { return fmaxf((v - ms.x) * ms.y, 0.f); }
 };
 
-template <class T>
-__global__ __launch_bounds__(T::THREADS, 2) void mlp3_sp_kernel(const float* __restrict__ sc, const float* __restrict__ b3,
+template <class T, int SCHED = 0>
+__global__ __launch_bounds__(T::THREADS, (T::NST == 2 ? 3 : 2)) void mlp3_sp_kernel(const float* __restrict__ sc, const float* __restrict__ b3,
                                                               const unsigned short* __restrict__ P0, const unsigned short* __restrict__ P1,
                                                               const unsigned short* __restrict__ P2, const float* __restrict__ U,
                                                               const float* __restrict__ stats, float* __restrict__ Z, ColLayout L) {
@@ -380,12 +393,8 @@ __global__ __launch_bounds__(T::THREADS, 2) void mlp3_sp_kernel(const float* __r
     const float sA = T::F16 ? sc[2] : 1.f;
     const float scale = sA * T::ACT_SCALE, inv = 1.f / scale;
     // statistics table behind the ring
-    float2* tab = reinterpret_cast<float2*>(smem_c + T::RING_BYTES);
-    {
-        const float* mean = stats + ((size_t)ts.seg * 2 + 0) * 512;
-        const float* rstd = stats + ((size_t)ts.seg * 2 + 1) * 512;
-        for (int c = tid; c < 512; c += T::THREADS) tab[c] = make_float2(mean[c], rstd[c] * T::ACT_SCALE);
-    }
+    float* tab = reinterpret_cast<float*>(smem_c + T::RING_BYTES);   // mean[512] | rstd[512]: four LDS-DMA pieces in front of the first slabs
+    static_assert(T::WAVES >= 4, "statistics table fill: one piece per wave");
     // start from (residual + bias) x the accumulator scale (exact: a power of two)
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -401,7 +410,11 @@ __global__ __launch_bounds__(T::THREADS, 2) void mlp3_sp_kernel(const float* __r
     SpPlainHooks<false> hooks;
     InstNormBx bx;
     bx.tab = tab;
-    gemm_mainloop_sp<T, 512 / BK>(reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, bx);
+    auto pre = [&]() {
+        if (wave < 4) glds16(stats + (size_t)ts.seg * 2 * 512 + wave * 256 + 4 * lane, tab + wave * 256);
+    };
+    gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), SpPlainHooks<false>, InstNormBx, 0, SCHED, decltype(pre)>(
+        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, bx, nullptr, pre);
     store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [inv](int, float v) { return v * inv; });
 }
 
@@ -440,9 +453,9 @@ __global__ __launch_bounds__(T::THREADS, 3) void score_exp_sp_kernel(const unsig
     const float inv = T::F16 ? 1.f / (T::ACT_SCALE * T::ACT_SCALE) : 1.f;   // both operands carry the scale
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
-    constexpr int TS = T::BN + 1;
+    constexpr int TS = T::BN + 4;   // conflict-free 16-byte row reads (see mlp0_sp_kernel)
     static_assert(T::BM * TS * 4 <= T::RING_BYTES, "the output tile is staged in the ring");
-    float* Tl = smem;  // [128][65]
+    float* Tl = smem;  // [128][68]
     float* cf = conf + (size_t)frame * L.n1 * L.n2;
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
@@ -459,11 +472,7 @@ __global__ __launch_bounds__(T::THREADS, 3) void score_exp_sp_kernel(const unsig
         for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
             const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
             const int gi = rt * T::BM + row, gj = ct * T::BN + c4;
-            if (gi < L.n1 && gj < L.n2) {
-                const float* t = Tl + row * TS + c4;
-                vf4 v = {t[0], t[1], t[2], t[3]};
-                *reinterpret_cast<vf4*>(cf + (size_t)gi * L.n2 + gj) = v;
-            }
+            if (gi < L.n1 && gj < L.n2) *reinterpret_cast<vf4*>(cf + (size_t)gi * L.n2 + gj) = *reinterpret_cast<const vf4*>(Tl + row * TS + c4);
         }
     } else {
         for (int idx = tid; idx < T::BM * T::BN; idx += T::THREADS) {
@@ -474,11 +483,13 @@ __global__ __launch_bounds__(T::THREADS, 3) void score_exp_sp_kernel(const unsig
     }
     {   // row sums: THREADS / BM lanes per row; column sums: THREADS / BN row groups, one thread per (group, column); fixed order
         constexpr int LPR = T::THREADS / T::BM, CPL = T::BN / LPR;
+        static_assert(LPR == 2 && CPL == 32, "walk skew of the row sums (rows 4 banks apart, the two lanes of a row 32 banks apart)");
         const int row = tid / LPR, hp = tid % LPR;
         const float* tr = Tl + row * TS + hp * CPL;
+        const int skew = hp + 2 * ((row >> 3) & 1);
         float s = 0.f;
 #pragma unroll 8
-        for (int m = 0; m < CPL; ++m) s += tr[m];
+        for (int m = 0; m < CPL; ++m) s += tr[(m + skew) % CPL];
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
         if (hp == 0 && rt * T::BM + row < L.n1p) rowpart[((size_t)frame * nct + ct) * L.n1p + rt * T::BM + row] = s;
@@ -522,11 +533,25 @@ static PlaneSet planes(const unsigned short* wb, int prec, size_t hi, size_t lo,
     return {wb + hi, wb + lo, wb + lo2};
 }
 
+// schedule of the split loop in the fp16 modes: 2 (default) = DMA requests spread over the step, 0 = in one burst behind the barrier (gemm_split_glds.h)
+static int sp_sched() {
+    // 2 measured 1.0-1.4 % faster per frame than 0 in interleaved single-process A/B runs (profiles/r04_ab_live_*.txt)
+    return tuning_knob("SP_SCHED", 2);   // (read per launch: tools/ab_live.py flips it inside one process)
+}
+
 template <int MODE>
 static void launch_qkv_sp_t(const float* sc, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     using T = QkvSpTile<MODE>;
-    allow_big_lds_sp<qkv_kv_sp_kernel<T>>();
     const PlaneSet p = planes(wb, MODE, AttnWB::QKV_HI, AttnWB::QKV_LO, AttnWB::QKV_LO2, AttnWB::QKV_H16, AttnWB::QKV_L16);
+    if constexpr (MODE >= 3) {
+        if (sp_sched() == 2) {
+            allow_big_lds_sp<qkv_kv_sp_kernel<T, 2>>();
+            GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 2>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s,
+                           sc, bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
+            return;
+        }
+    }
+    allow_big_lds_sp<qkv_kv_sp_kernel<T>>();
     GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s, sc,
                    bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
 }
@@ -553,10 +578,10 @@ static void launch_mlp0_sp_m(const float* sc, const float* b0, const unsigned sh
     // its 4 x tiles workgroups make ONE round of the 256 CUs and fill at least three quarters of it (the headline shape: 252); with
     // fewer the 64-column tile (4 waves, two workgroups per CU, twice as many) fills the chip better, with more than one round its
     // co-resident pairs overlap one workgroup's store tail with the other's loop (fp16x4, 8 frames per step: 179 vs 188 us per launch)
-    static const int wide_min = tuning_knob("SP_MLP0_WIDE_MIN", 48), wide_max = tuning_knob("SP_MLP0_WIDE_MAX", 64);
+    const int wide_min = tuning_knob("SP_MLP0_WIDE_MIN", 48), wide_max = tuning_knob("SP_MLP0_WIDE_MAX", 64);   // (per launch: tools/ab_live.py)
 #ifdef GATSSPG_TUNING
     if constexpr (MODE == 4) {   // timing-only ablations of the main loop (wrong results)
-        static const int abl = tuning_knob("SP_ABL", 0);
+        const int abl = tuning_knob("SP_ABL", 0);
         switch (abl) {
             case 1: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 1>(sc, b0, wb, w, s, hk);     // no DMA after the prologue
             case 2: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 2>(sc, b0, wb, w, s, hk);     // no MFMAs
@@ -577,7 +602,18 @@ static void launch_mlp0_sp_m(const float* sc, const float* b0, const unsigned sh
         }
     }
 #endif
-    if (active_tiles(w.L) / 2 >= wide_min && active_tiles(w.L) / 2 <= wide_max) launch_mlp0_sp_t<Mlp0SpTileW<MODE>>(sc, b0, wb, w, s, hk);
+    const bool wide = active_tiles(w.L) / 2 >= wide_min && active_tiles(w.L) / 2 <= wide_max;
+    if constexpr (MODE == 4) {
+        if (tuning_knob("SP_NST2", 0) & 1) return launch_mlp0_sp_t<Mlp0SpTileN2<MODE>, 0, 2>(sc, b0, wb, w, s, hk);   // three workgroups per CU
+    }
+    if constexpr (MODE >= 3) {
+        if (sp_sched() == 2) {
+            if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 2>(sc, b0, wb, w, s, hk);
+            else launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 2>(sc, b0, wb, w, s, hk);
+            return;
+        }
+    }
+    if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>>(sc, b0, wb, w, s, hk);
     else launch_mlp0_sp_t<Mlp0SpTileN<MODE>>(sc, b0, wb, w, s, hk);
 }
 void launch_mlp0_sp(const float* sc, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
@@ -592,9 +628,26 @@ void launch_mlp0_sp(const float* sc, const float* b0, const unsigned short* wb, 
 template <int MODE>
 static void launch_mlp3_sp_t(const float* sc, const float* b3, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     using T = Mlp3SpTile<MODE>;
-    allow_big_lds_sp<mlp3_sp_kernel<T>>();
     const PlaneSet p = planes(wb, MODE, AttnWB::W3_HI, AttnWB::W3_LO, AttnWB::W3_LO2, AttnWB::W3_H16, AttnWB::W3_L16);
     const int NT = active_tiles(w.L) / (T::BN / 64);
+    if constexpr (MODE == 4) {
+        if (tuning_knob("SP_NST2", 0) & 2) {
+            using T2 = Mlp3SpTile2<MODE>;
+            allow_big_lds_sp<mlp3_sp_kernel<T2, 2>>();
+            GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T2, 2>), dim3(xcd_grid(256 / T2::BM, NT)), dim3(T2::THREADS), (size_t)T2::RING_BYTES + 4096, s,
+                           sc, b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
+            return;
+        }
+    }
+    if constexpr (MODE >= 3) {
+        if (sp_sched() == 2) {
+            allow_big_lds_sp<mlp3_sp_kernel<T, 2>>();
+            GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, 2>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc,
+                           b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
+            return;
+        }
+    }
+    allow_big_lds_sp<mlp3_sp_kernel<T>>();
     GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc, b3,
                    p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
 }

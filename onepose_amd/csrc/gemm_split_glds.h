@@ -175,7 +175,7 @@ struct SpNoHooks {
     __device__ __forceinline__ void in_step(f32x16 (&)[TM]) {}
 };
 // BX: per-k-row transform of the B values before the split (mlp.3: InstanceNorm + ReLU); fetch(k, x) reads the 8 per-row aux pairs
-// of rows k .. k + 7 (the lane's own k run), apply(v, x) returns the value to split (activation pre-scale INCLUDED).
+// of rows k .. k + 7 (the lane's own k run), apply(v, x) returns the value to split (the activation pre-scale is applied by the split).
 struct SpNoBx {
     static constexpr bool ON = false;
     __device__ __forceinline__ void fetch(int, float2 (&)[8]) const {}
@@ -200,9 +200,20 @@ constexpr int SP_TRACE_STEP = 5;
 //   of slab I, c(I) = splits + products of slab I, and ONE barrier per slab -- the early group behind c(I), the late group behind
 //   m(I).  Between two barriers each wave does one m and one c, the groups in opposite order: while one wave of a SIMD multiplies,
 //   its partner requests and reads, and only half of the workgroup loads the CU's DMA / LDS paths at a time.
-template <class T, int KT, class APlane, class BSlab, class Hooks, class BX, int ABL = 0, int SCHED = 0>
+// pre(): called once, right BEFORE the DMA requests of the first NST slabs -- the place for LDS-DMA fills of small per-workgroup tables
+// (glds16 pieces: being older than every slab piece they are covered by the first counted wait and published by the first barrier; a
+// table filled through registers would stall the wave on its load in front of the first slab requests).
+struct SpNoPre {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <class T, int KT, class APlane, class BSlab, class Hooks, class BX, int ABL = 0, int SCHED = 0, class Pre = SpNoPre>
 __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* smem, APlane a_pl, BSlab b_slab, int ldb, Hooks& hooks,
-                                                 BX& bx, SpTrace* tr = nullptr) {
+                                                 BX& bx, SpTrace* tr_ = nullptr, Pre pre = Pre(), bool tron = false) {
+    // (profiling builds: the stamps go into the caller's SpTrace through a reference and a separate on/off flag -- a conditional pointer
+    //  keeps the object in scratch memory and costs the traced kernel 50 spilled registers)
+    SpTrace tr_dummy;
+    SpTrace& trr = tr_ ? *tr_ : tr_dummy;
+    (void)trr; (void)tron;
     constexpr int TM = T::TM, PA = T::PA, BN = T::BN, NST = T::NST, G = T::G, MODE = T::MODE;
     static_assert(KT >= NST, "at least NST slabs");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -218,10 +229,12 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
     constexpr int KPP = 64 / LPR;      // k rows per B piece
     const unsigned b_lane = (unsigned)(((lane / LPR) * ldb + (lane % LPR) * 4) * 4);
     constexpr int RPP = T::BM / 16;    // A pieces per plane
-    auto issue = [&](int kt, int stage) {
+    // pieces [j0, j1) of this wave's G pieces of slab kt
+    auto issue_pieces = [&](int kt, int stage, int j0, int j1) {
         char* st = smem + stage * T::STAGE_BYTES;
 #pragma unroll
         for (int j = 0; j < G; ++j) {
+            if (j < j0 || j >= j1) continue;
             const int q = j * T::WAVES + wave;   // wave-uniform
             const bool is_a = (T::NA % T::WAVES == 0) ? (j < T::NA / T::WAVES) : (q < T::NA);
             if (is_a) {
@@ -234,6 +247,7 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
             }
         }
     };
+    auto issue = [&](int kt, int stage) { issue_pieces(kt, stage, 0, G); };
 
     // ---- fragment read offsets (bytes inside a stage)
     int a_off[TM][2];
@@ -293,10 +307,8 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
         if constexpr (BX::ON) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = bx.apply(v[j], Bx[P][j]);
-            split8<MODE>(v, Bf[P]);                       // the transform already carries the activation pre-scale
-        } else {
-            split8<MODE>(v, Bf[P], T::ACT_SCALE);         // fp16 modes: scaled inside the split; bf16 modes: ACT_SCALE = 1
         }
+        split8<MODE>(v, Bf[P], T::ACT_SCALE);   // fp16 modes: scaled inside the split; bf16 modes: ACT_SCALE = 1
     };
     auto mfma_part = [&](auto Ic, auto Pc, int tm0, int tm1) {
         constexpr int I = decltype(Ic)::value, P = decltype(Pc)::value;
@@ -329,11 +341,12 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
     // sched_barrier(0) pins the bracketed groups; inside a group hipcc interleaves VALU, LDS reads and MFMAs by itself.
     auto stamp = [&](int I, int k) {   // (compiled out unless the caller passes a trace object: profiling builds)
 #ifdef GATSSPG_PROFILING_BUILD
-        if (tr && (I == SP_TRACE_STEP || k == 0 || k == 8)) tr->t[k] = __builtin_readcyclecounter();
+        if (tron && (I == SP_TRACE_STEP || k == 0 || k == 8)) trr.t[k] = __builtin_readcyclecounter();
 #else
-        (void)I; (void)k; (void)tr;
+        (void)I; (void)k;
 #endif
     };
+    pre();
     static_for<0, NST>([&](auto Ic) { issue(decltype(Ic)::value, decltype(Ic)::value); });
     wait_dma_barrier<(NST - 1) * G>();
     if constexpr (SCHED == 1) {
@@ -373,6 +386,71 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
         __builtin_amdgcn_sched_barrier(0);
         stamp(-1, 8);
         wait_dma_barrier<0>();   // every wave is done with the ring: the epilogue may re-use it
+        return;
+    }
+    if constexpr (SCHED == 2) {
+        // SCHED 0 with the DMA requests of a step SPREAD over it instead of issued in one burst behind the barrier (where all waves of
+        // the workgroup hit the CU's DMA path at once: ~140 cycles per piece in the trace): slot 0 behind the barrier, slot 1 between
+        // the two halves of products (I, P1), slot 2 behind them, slot 3 (three-stage rings only: the slab has a whole further step to
+        // land) inside the next step's first product group.  The raw B values of (I + 1, P1) are read between the halves as well.
+        constexpr int NSLOT = NST == 3 ? 4 : 3;
+        constexpr int E0 = (G + NSLOT - 1) / NSLOT, E1 = E0 + (G - E0 + NSLOT - 2) / (NSLOT - 1);
+        constexpr int E2 = NSLOT == 3 ? G : E1 + (G - E1 + 1) / 2;
+        read_b(0, 0, IC<0>{});
+        read_b(0, 0, IC<1>{});
+        read_a(0, IC<0>{});
+        read_a(0, IC<1>{});
+        split_part(IC<0>{}, IC<0>{});
+        stamp(-1, 0);
+        static_for<0, KT>([&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (I == SP_TRACE_STEP) stamp(I, 1);
+            mfma_part(Ic, IC<0>{}, 0, TM / 2);
+            if constexpr (E2 < G && I >= 1 && I - 1 + NST < KT && !(ABL & 1)) {   // slot 3 of the slab requested in step I - 1
+                __builtin_amdgcn_sched_barrier(0);
+                issue_pieces(I - 1 + NST, (I - 1) % NST, E2, G);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mfma_part(Ic, IC<0>{}, TM / 2, TM);
+            split_part(Ic, IC<1>{});
+            if constexpr (Hooks::ENABLED) hooks.template in_step<I, TM>(acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (I == SP_TRACE_STEP) stamp(I, 2);
+            if constexpr (I + 1 < KT) {
+                constexpr int LATER = (I + NST - 1 < KT - 1 ? I + NST - 1 : KT - 1) - (I + 1);
+                wait_dma_barrier<LATER * G>();
+                if constexpr (I == SP_TRACE_STEP) stamp(I, 3);
+                if constexpr (I + NST < KT && !(ABL & 1)) issue_pieces(I + NST, I % NST, 0, E0);
+                read_b((I + 1) % NST, I + 1, IC<0>{});
+                read_a((I + 1) % NST, IC<0>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (I == SP_TRACE_STEP) stamp(I, 4);
+            mfma_part(Ic, IC<1>{}, 0, TM / 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (I + 1 < KT) {
+                if constexpr (I + NST < KT && !(ABL & 1)) issue_pieces(I + NST, I % NST, E0, E1);
+                read_b((I + 1) % NST, I + 1, IC<1>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (I == SP_TRACE_STEP) stamp(I, 5);
+            mfma_part(Ic, IC<1>{}, TM / 2, TM);
+            if constexpr (I + 1 < KT) split_part(IC<I + 1>{}, IC<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (I == SP_TRACE_STEP) stamp(I, 6);
+            if constexpr (I + 1 < KT) {
+                if constexpr (I + NST < KT && !(ABL & 1)) issue_pieces(I + NST, I % NST, E1, E2);
+                read_a((I + 1) % NST, IC<1>{});
+            }
+            if constexpr (I == SP_TRACE_STEP) {
+                __builtin_amdgcn_sched_barrier(0);
+                stamp(I, 7);
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(-1, 8);
+        wait_dma_barrier<0>();
         return;
     }
     read_b(0, 0, IC<0>{});
