@@ -170,11 +170,12 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel
 //     partial (0 + x = x: same bits as reducing the partials again).
 constexpr int KVP4 = KVP / 4;
 static_assert(KVP % 4 == 0, "KV partials are summed as float4");
-constexpr int KVF_RS = 2;                       // row halves of M_t per d block: two workgroups repeat the (cheap, parallel) reduction and
-constexpr int KVF_ROWS = 512 / KVF_RS;          //   each turns it into 256 rows of the operator -> 264 workgroups, every CU busy
-constexpr int KVF_BLOCKS = 16 * KVF_RS + 1;     // 16 d-row blocks x row halves + the ksum block
+// KVF_RS: row parts of M_t per d block.  2: two workgroups repeat the (cheap, parallel) reduction and each turns it into 256 rows of the
+// operator with its first 512 threads (264 workgroups, every CU busy).  1: one workgroup per d block, all 1024 threads in the operator
+// phase, every partial read once (136 workgroups, half the bytes).
 
 // abl (tuning builds only, wrong results, 0 in the product): bit 0 no FMA phase, bit 1 no operator stores, bit 2 no weight loads
+template <int KVF_RS>
 __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict__ kvpart, const float* __restrict__ kv_src,
                                                         float* __restrict__ kvfin, const float* __restrict__ W0,
                                                         float* __restrict__ Mop, unsigned short* __restrict__ Mpl,
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
                                                         const float* __restrict__ sc, ColLayout L, int cross, int prec, int abl) {
     __shared__ float4 red[16][64];
     __shared__ float4 kvs[64];   // this block's final KV^T rows: [4 d][16 float4 of q]
+    constexpr int KVF_ROWS = 512 / KVF_RS;
     if (prec >= 3) fp16_saturate_mode();
     const int tid = threadIdx.x;
     const int el = tid & 63, part = tid >> 6;
@@ -200,10 +202,10 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
     const float mscale = prec >= 3 ? sc[1] * __builtin_ldexpf(1.f, -mexp) : 1.f;
     // operator phase: thread = (row pair rp, q quarter qq); lane qq takes the float4s qq, qq + 4, qq + 8, qq + 12 of the 64 q of a
     // row (the 4 lanes of a row read 64 contiguous bytes per load).  The weights do not depend on the reduction: requested first.
-    const int rp = (tid >> 2) & 127, qq = tid & 3;
+    const int rp = (tid >> 2) & (KVF_ROWS / 2 - 1), qq = tid & 3;
     const int mr = rs * KVF_ROWS + 2 * rp;
     vf4 wv[2][4];
-    const bool op_thread = !ksum_block && tid < 512;
+    const bool op_thread = !ksum_block && tid < 2 * KVF_ROWS;
     if (op_thread && !(abl & 4)) {
         const float* wr = W0 + (size_t)mr * 512 + 256 + h * DH + 4 * qq;
 #pragma unroll
@@ -946,8 +948,16 @@ bool split_loop_glds(int prec) {
     return prec >= 3 || (prec == 1 && b3 != 0) || (prec == 2 && b6 != 0);
 }
 
+// fp32 arithmetic on the LDS-DMA loop (tuning builds: GATSSPG_FP32_DMA, bit 0 qkv_kv, 1 mlp0, 2 mlp3); shapes whose launches leave CUs
+// empty keep the K-split tiles of the register-staged loop
+static int fp32_dma(const Workspace& w) {
+    const int m = tuning_knob("FP32_DMA", 0);
+    return (w.prec == 0 && active_tiles(w.L) > 64) ? m : 0;
+}
+
 void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s,
                    ProfileHook* hk) {
+    if (fp32_dma(w) & 1) return launch_qkv_kv_dma(Wqkv, bqkv, w, s, hk);
     if (split_loop_glds(w.prec)) {
         // Wqkv is the first member of the layer's AttnW block: its scales sit at AttnW::SC from there
         launch_qkv_kv_sp(Wqkv - AttnW::WQKV + AttnW::SC, bqkv, wb, w, s, hk);
@@ -962,7 +972,14 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* w
 
 void launch_kv_final(const float* W0, const Workspace& w, int cross, const float* kv_src, hipStream_t s, ProfileHook* hk) {
     static const int abl = tuning_knob("KVF_ABL", 0);   // tuning builds: timing-only ablations of the operator phase
-    GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel, dim3(KVF_BLOCKS, w.nseg * H), dim3(1024), 0, s, w.kvpart, kv_src, w.kvfin,
+    // one workgroup per d block by default since round 4: every partial read once (interleaved A/B, profiles/r04_ab_live_kv_final.txt: kernel
+    // 11.4 -> 10.5 us event-timed, +0.7 ... +1.6 % frames/s in flight at the three shapes, bit-identical results); KVF_RS=2: the two-row-half form
+    if (tuning_knob("KVF_RS", 1) == 1) {
+        GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel<1>, dim3(17, w.nseg * H), dim3(1024), 0, s, w.kvpart, kv_src, w.kvfin, W0, w.Mop, w.Mpl,
+                       w.ksumT, w.zsc, w.statcnt, W0 - AttnW::W0 + AttnW::SC, w.L, cross, w.prec, abl);
+        return;
+    }
+    GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel<2>, dim3(33, w.nseg * H), dim3(1024), 0, s, w.kvpart, kv_src, w.kvfin,
                    W0, w.Mop, w.Mpl, w.ksumT, w.zsc, w.statcnt, W0 - AttnW::W0 + AttnW::SC, w.L, cross, w.prec, abl);
 }
 
@@ -1001,7 +1018,9 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     (void)t0;
     const bool sp = split_loop_glds(w.prec);
     const float* sc = W0 - AttnW::W0 + AttnW::SC;
-    if (sp) launch_mlp0_sp(sc, b0, wb, w, s, hk);
+    const int dma = fp32_dma(w);
+    if (dma & 2) launch_mlp0_dma(W0, b0, w, s, hk);
+    else if (sp) launch_mlp0_sp(sc, b0, wb, w, s, hk);
     else if (small0 && t0 == 0) launch_mlp0_t<Mlp0TileS, 0, 0>(W0, b0, wb, w, s, hk);
     else if (w.prec == 1) launch_mlp0_t<Mlp0TileW8, 0, 1>(W0, b0, wb, w, s, hk);
     else if (w.prec == 2) launch_mlp0_t<Mlp0TileW8, 0, 2>(W0, b0, wb, w, s, hk);
@@ -1015,7 +1034,8 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     // (the InstanceNorm statistics are finished inside the mlp.0 launch by its last workgroups: stat_last_block; tuning builds keep the
     //  separate reducer launch for A/B runs, GATSSPG_STAT_FUSED=0)
     if (!stat_fused()) GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
-    if (sp) launch_mlp3_sp(sc, b3, wb, w, s, hk);
+    if (dma & 4) launch_mlp3_dma(W3, b3, w, s, hk);
+    else if (sp) launch_mlp3_sp(sc, b3, wb, w, s, hk);
     else if (small3 && t3 == 1) launch_mlp3_t<Mlp3TileS, 0, 0>(W3, b3, wb, w, s, hk);
     else if (w.prec == 1 && t3 == 0) launch_mlp3_t<Mlp3Tile, 0, 1>(W3, b3, wb, w, s, hk);
     else if (w.prec == 1) launch_mlp3_t<Mlp3TileTallW8, 0, 1>(W3, b3, wb, w, s, hk);

@@ -60,6 +60,10 @@ void launch_mlp3_sp(const float* sc, const float* b3, const unsigned short* pack
 bool score_on_split_loop(int prec, int shifted);
 void launch_score_exp_sp(const Workspace& w, float* conf, float scale, hipStream_t s, ProfileHook* hk = nullptr);
 constexpr int SCORE_SPLIT_SCALE_LOG2 = 10;   // unit-norm descriptors (|x| <= 1) are multiplied by 2^10 before the fp16 split
+// the fp32 arithmetic (exact v_mfma_f32_32x32x2_f32) on the LDS-DMA loop: same kernels, MODE 0, the fp32 operators as the A operand
+void launch_qkv_kv_dma(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_mlp0_dma(const float* W0, const float* b0, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
+void launch_mlp3_dma(const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 // true if the split-precision launch goes to the kernels above (fp16 modes: always; bf16 modes: unless a tuning build says otherwise)
 bool split_loop_glds(int prec);
 // true: the InstanceNorm statistics are finished inside the mlp.0 launch (no stat_final launch); false only in tuning builds

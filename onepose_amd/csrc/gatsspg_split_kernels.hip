@@ -58,9 +58,12 @@ __device__ __forceinline__ void load_bias16(const float* b, int row0, int wm, in
 // =====================================================================================================
 template <int MODE>
 using QkvSpTile = SpTile<128, 2, 2, 2, MODE>;
+// the exact fp32 MFMA on the same loop (MODE 0): 128 x 64 on 8 waves of 32 x 32 like the fp32 kernels of gatsspg_gemm_kernels.hip (two
+// workgroups per CU, <= 128 registers), three stages of 24 KiB
+using Fp32SpTile = SpTile<128, 4, 2, 3, 0>;
 
 template <class T, int SCHED = 0>
-__global__ __launch_bounds__(T::THREADS, 3) void qkv_kv_sp_kernel(const float* __restrict__ sc, const float* __restrict__ bqkv,
+__global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : 3)) void qkv_kv_sp_kernel(const float* __restrict__ sc, const float* __restrict__ bqkv,
                                                                 const unsigned short* __restrict__ P0, const unsigned short* __restrict__ P1,
                                                                 const unsigned short* __restrict__ P2, const float* __restrict__ Z,
                                                                 float* __restrict__ Qbuf, float* __restrict__ kvpart, ColLayout L) {
@@ -78,12 +81,16 @@ __global__ __launch_bounds__(T::THREADS, 3) void qkv_kv_sp_kernel(const float* _
     const float inv = T::F16 ? 1.f / (sc[0] * T::ACT_SCALE) : 1.f;
     f32x16 acc[T::TM][T::TN];
     const size_t ro = (size_t)rt * 128 * BK;
-    auto apl = [&](int kt, int pl) { return (pl == 0 ? P0 : pl == 1 ? P1 : P2) + ro + (size_t)kt * 768 * BK; };
+    // 16-bit modes: slab-major planes; fp32 (MODE 0): P0 is the row-major fp32 operator [768][256] itself
+    auto apl = [&](int kt, int pl) -> const void* {
+        if constexpr (T::F32) return reinterpret_cast<const float*>(P0) + (size_t)rt * 128 * D + kt * BK;
+        else return (pl == 0 ? P0 : pl == 1 ? P1 : P2) + ro + (size_t)kt * 768 * BK;
+    };
     auto bsl = [&](int kt) { return Z + (size_t)kt * BK * ld + c0; };
     SpPlainHooks<true> hooks;
     SpNoBx nobx;
-    gemm_mainloop_sp<T, D / BK, decltype(apl), decltype(bsl), SpPlainHooks<true>, SpNoBx, 0, SCHED>(reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c,
-                                                                                                 apl, bsl, ld, hooks, nobx);
+    gemm_mainloop_sp<T, D / BK, decltype(apl), decltype(bsl), SpPlainHooks<true>, SpNoBx, 0, SCHED>(
+        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx, nullptr, SpNoPre(), false, T::F32 ? D * 4 : 64);
 
     if (rt < 2) {
 #pragma unroll
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(T::THREADS, 3) void qkv_kv_sp_kernel(const float* _
     const int h = rt - 2;
     const TileSeg ts = tile_seg(L, c0, T::BN);
     constexpr int TS = T::BN + 4;
-    static_assert(T::BN == QKV_BN && T::WAVES == 4 && 128 * TS * 4 <= T::RING_BYTES, "one KV partial per 64-column tile, four waves");
+    static_assert(T::BN == QKV_BN && T::WAVES >= 4 && 128 * TS * 4 <= T::RING_BYTES, "one KV partial per 64-column tile");
     float* Tl = smem;
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(T::THREADS, 3) void qkv_kv_sp_kernel(const float* _
             Tl[row * TS + col] = v;
         }
     __syncthreads();
-    {
+    if (wave < 4) {   // (an 8-wave workgroup leaves this short pass to its first four waves)
         const int qi = wave >> 1, di = wave & 1;
         f32x16 kv;
 #pragma unroll
@@ -213,7 +220,7 @@ template <int MODE>
 using Mlp0SpTileT = SpTile<128, 1, 4, 3, MODE>;   // 128 x 128 on 4 waves, 128 x 32 per wave (one wave per SIMD, every B value split once)
 
 template <class T, int ABL = 0, int SCHED = 0>
-__global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : (T::WAVES == 4 && T::NST == 2) ? 3 : 2)) void mlp0_sp_kernel(const float* __restrict__ sc, const float* __restrict__ b0,
+__global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::TM == 4 ? 1 : (T::WAVES == 4 && T::NST == 2) ? 3 : 2)) void mlp0_sp_kernel(const float* __restrict__ sc, const float* __restrict__ b0,
                                                               const unsigned short* __restrict__ P0, const unsigned short* __restrict__ P1,
                                                               const unsigned short* __restrict__ P2, const float* __restrict__ Z,
                                                               const float* __restrict__ Qbuf, const unsigned short* __restrict__ Mpl,
@@ -246,8 +253,17 @@ __global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : (T::WAVES == 4 && T::
     f32x16 acc[T::TM][T::TN];
     const size_t ro = (size_t)rt * T::BM * BK;   // slab-major planes: (m, k) at ((k / 32) * 512 + m) * 32 + k % 32
     const unsigned short* Mh = Mpl + (size_t)ts.seg * 3 * MPL_PLANE + ro;
-    auto apl = [&](int kt, int pl) {
-        return kt < 8 ? (pl == 0 ? P0 : pl == 1 ? P1 : P2) + ro + (size_t)kt * 512 * BK : Mh + (size_t)pl * MPL_PLANE + (size_t)(kt - 8) * 512 * BK;
+    // 16-bit modes: slab-major planes of W0 (x half) and of the segment's message operator; fp32 (MODE 0): P0 = the fp32 [512][512] operator,
+    // Mpl = the fp32 operator block Mop (the segment's M_t at mop_seg(), row stride MOP_LD = 512 like W0)
+    auto apl = [&](int kt, int pl) -> const void* {
+        if constexpr (T::F32) {
+            const float* W0f = reinterpret_cast<const float*>(P0) + (size_t)rt * T::BM * 512;
+            const float* Mf = mop_seg(reinterpret_cast<const float*>(Mpl), ts.seg) + (size_t)rt * T::BM * MOP_LD;
+            return kt < 8 ? W0f + kt * BK : Mf + (kt - 8) * BK;
+        } else {
+            return kt < 8 ? (pl == 0 ? P0 : pl == 1 ? P1 : P2) + ro + (size_t)kt * 512 * BK
+                          : Mh + (size_t)pl * MPL_PLANE + (size_t)(kt - 8) * 512 * BK;
+        }
     };
     auto bsl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : Qbuf + (size_t)(kt - 8) * BK * ld) + c0; };
     AttnFoldSp<T::TM> hooks;
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(T::THREADS, (T::TM == 4 ? 1 : (T::WAVES == 4 && T::
         if (wave == 0) glds16(ksumT + (size_t)ts.seg * H * DH + 4 * lane, tab);   // [4][64] floats = 1 KiB
     };
     gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), AttnFoldSp<T::TM>, SpNoBx, ABL, SCHED, decltype(pre)>(
-        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx, &tr, pre, SP_TRACE_ON(trace));
+        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx, &tr, pre, SP_TRACE_ON(trace), T::F32 ? 512 * 4 : 64);
     if (SP_TRACE_ON(trace)) tr.t[9] = __builtin_readcyclecounter();    // behind the loop's last barrier
     hooks.template fold<3>(reinterpret_cast<f32x16(&)[T::TM]>(acc));
     if constexpr (ABL & 32) {   // timing only: no epilogue at all (one store keeps the accumulators alive)
@@ -374,7 +390,7 @@ struct InstNormBx {
 };
 
 template <class T, int SCHED = 0>
-__global__ __launch_bounds__(T::THREADS, (T::NST == 2 ? 3 : 2)) void mlp3_sp_kernel(const float* __restrict__ sc, const float* __restrict__ b3,
+__global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::NST == 2 ? 3 : 2)) void mlp3_sp_kernel(const float* __restrict__ sc, const float* __restrict__ b3,
                                                               const unsigned short* __restrict__ P0, const unsigned short* __restrict__ P1,
                                                               const unsigned short* __restrict__ P2, const float* __restrict__ U,
                                                               const float* __restrict__ stats, float* __restrict__ Z, ColLayout L) {
@@ -405,7 +421,10 @@ __global__ __launch_bounds__(T::THREADS, (T::NST == 2 ? 3 : 2)) void mlp3_sp_ker
             acc[tm][0][r] = (Z[(size_t)row * ld + c0 + wn * 32 + l31] + b3[row]) * scale;
         }
     const size_t ro = (size_t)rt * T::BM * BK;
-    auto apl = [&](int kt, int pl) { return (pl == 0 ? P0 : pl == 1 ? P1 : P2) + ro + (size_t)kt * 256 * BK; };
+    auto apl = [&](int kt, int pl) -> const void* {
+        if constexpr (T::F32) return reinterpret_cast<const float*>(P0) + (size_t)rt * T::BM * 512 + kt * BK;   // fp32 W3 [256][512]
+        else return (pl == 0 ? P0 : pl == 1 ? P1 : P2) + ro + (size_t)kt * 256 * BK;
+    };
     auto bsl = [&](int kt) { return U + (size_t)kt * BK * ld + c0; };
     SpPlainHooks<false> hooks;
     InstNormBx bx;
@@ -414,7 +433,7 @@ __global__ __launch_bounds__(T::THREADS, (T::NST == 2 ? 3 : 2)) void mlp3_sp_ker
         if (wave < 4) glds16(stats + (size_t)ts.seg * 2 * 512 + wave * 256 + 4 * lane, tab + wave * 256);
     };
     gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), SpPlainHooks<false>, InstNormBx, 0, SCHED, decltype(pre)>(
-        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, bx, nullptr, pre);
+        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, bx, nullptr, pre, false, T::F32 ? 512 * 4 : 64);
     store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [inv](int, float v) { return v * inv; });
 }
 
@@ -555,6 +574,27 @@ static void launch_qkv_sp_t(const float* sc, const float* bqkv, const unsigned s
     GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s, sc,
                    bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
 }
+// fp32 (MODE 0): Wqkv is the fp32 operator itself
+void launch_qkv_kv_dma(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    using T = Fp32SpTile;
+    allow_big_lds_sp<qkv_kv_sp_kernel<T, 2>>();
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 2>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s, Wqkv,
+                   bqkv, reinterpret_cast<const unsigned short*>(Wqkv), nullptr, nullptr, w.Z, w.Q, w.kvpart, w.L);
+}
+void launch_mlp0_dma(const float* W0, const float* b0, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    using T = Fp32SpTile;
+    allow_big_lds_sp<mlp0_sp_kernel<T, 0, 2>>();
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_sp_kernel<T, 0, 2>), dim3(xcd_grid(512 / T::BM, active_tiles(w.L))), dim3(T::THREADS),
+                   (size_t)T::RING_BYTES + 1024, s, W0, b0, reinterpret_cast<const unsigned short*>(W0), nullptr, nullptr, w.Z, w.Q,
+                   reinterpret_cast<const unsigned short*>(w.Mop), w.ksumT, w.zsc, w.U, w.statpart, w.stats, stat_fused() ? w.statcnt : nullptr, w.L, g_trace);
+}
+void launch_mlp3_dma(const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    using T = Fp32SpTile;
+    allow_big_lds_sp<mlp3_sp_kernel<T, 2>>();
+    GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, 2>), dim3(xcd_grid(256 / T::BM, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s,
+                   W3, b3, reinterpret_cast<const unsigned short*>(W3), nullptr, nullptr, w.U, w.stats, w.Z, w.L);
+}
+
 void launch_qkv_kv_sp(const float* sc, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     switch (w.prec) {
         case 1: launch_qkv_sp_t<1>(sc, bqkv, wb, w, s, hk); break;

@@ -61,16 +61,18 @@ __device__ __forceinline__ void wait_dma_barrier_if(int on) {
 
 constexpr int FP16_ACT_SCALE_LOG2 = 4;   // activations are multiplied by 2^4 before the fp16 split (exact), range +-8188
 
-// MODE = Workspace::prec: 1 bf16x3, 2 bf16x6, 3 fp16x3, 4 fp16x4
+// MODE = Workspace::prec: 1 bf16x3, 2 bf16x6, 3 fp16x3, 4 fp16x4; 0 = the exact fp32 MFMA (v_mfma_f32_32x32x2_f32) on the same loop: the A
+// operand is then the fp32 row-major matrix itself (128-byte LDS rows, chunk c of row r at c ^ ((r >> 1) & 7)), B is fed to the MFMAs unsplit.
 // ASL: log2 of the power of two the B operand (activations) is multiplied by before an fp16 split (ignored by the bf16 modes)
 template <int BM_, int WM_, int WN_, int NST_, int MODE_, int ASL_ = FP16_ACT_SCALE_LOG2>
 struct SpTile {
     static constexpr int BM = BM_, WM = WM_, WN = WN_, NST = NST_, MODE = MODE_;
     static constexpr int TM = BM / WM / 32, TN = 1, BN = 32 * WN;
     static constexpr int WAVES = WM * WN, WAVES_MN = WAVES, THREADS = 64 * WAVES, KS = 1;
-    static constexpr bool F16 = MODE >= 3;
-    static constexpr int PA = MODE == 2 ? 3 : 2;                  // 16-bit planes per operand
-    static constexpr int A_PLANE_BYTES = BM * 64;                 // [BM][32] 16-bit, unpadded, swizzled
+    static constexpr bool F16 = MODE >= 3, F32 = MODE == 0;
+    static constexpr int PA = F32 ? 1 : MODE == 2 ? 3 : 2;        // planes per operand (16-bit terms; fp32: the matrix itself)
+    static constexpr int ROW_BYTES = F32 ? 128 : 64;              // one LDS row = 32 k of one matrix row
+    static constexpr int A_PLANE_BYTES = BM * ROW_BYTES;          // [BM][32], unpadded, swizzled
     static constexpr int A_BYTES = PA * A_PLANE_BYTES;
     static constexpr int B_BYTES = BK * BN * 4;                   // raw fp32 [32][BN]
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
@@ -208,7 +210,8 @@ struct SpNoPre {
 };
 template <class T, int KT, class APlane, class BSlab, class Hooks, class BX, int ABL = 0, int SCHED = 0, class Pre = SpNoPre>
 __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* smem, APlane a_pl, BSlab b_slab, int ldb, Hooks& hooks,
-                                                 BX& bx, SpTrace* tr_ = nullptr, Pre pre = Pre(), bool tron = false) {
+                                                 BX& bx, SpTrace* tr_ = nullptr, Pre pre = Pre(), bool tron = false, int lda_bytes = 64) {
+    // lda_bytes: row stride of an A slab in bytes (slab-major 16-bit planes: 64; a row-major fp32 matrix: 4 x its leading dimension)
     // (profiling builds: the stamps go into the caller's SpTrace through a reference and a separate on/off flag -- a conditional pointer
     //  keeps the object in scratch memory and costs the traced kernel 50 spilled registers)
     SpTrace tr_dummy;
@@ -224,11 +227,16 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
     // ---- LDS-DMA pieces: piece q of a slab = 1 KiB of its LDS image; lane i supplies bytes [16 i, 16 i + 16) of it.
     // A piece: 16 rows x 64 B of one plane; LDS chunk position i & 3 of row i >> 2 holds source chunk (i & 3) ^ ((row >> 2) & 3),
     // and (row >> 2) & 3 = (i >> 4) & 3 because pieces start on multiples of 16 rows.
-    const unsigned a_lane = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+    // (fp32 rows are 128 bytes: a piece is 8 rows, the swizzle (row >> 1) & 7 = (4 (piece & 1)) | (lane >> 4): the lane part below, the
+    //  piece-parity part -- bit 2 of the chunk index = byte 64 -- is XORed in per piece)
+    constexpr int CPR = T::ROW_BYTES / 16;   // 16-byte chunks per row (4 or 8)
+    constexpr int RPQ = 64 / CPR;            // rows per piece (16 or 8)
+    const unsigned a_lane_row = (unsigned)(lane / CPR), a_lane_chunk = (unsigned)((lane % CPR) ^ ((lane >> 4) & 3));
+    const unsigned a_lane = a_lane_row * (unsigned)lda_bytes + a_lane_chunk * 16;
     constexpr int LPR = BN / 4;        // lanes per k row of a B piece (16 B each)
     constexpr int KPP = 64 / LPR;      // k rows per B piece
     const unsigned b_lane = (unsigned)(((lane / LPR) * ldb + (lane % LPR) * 4) * 4);
-    constexpr int RPP = T::BM / 16;    // A pieces per plane
+    constexpr int RPP = T::BM / RPQ;   // A pieces per plane
     // pieces [j0, j1) of this wave's G pieces of slab kt
     auto issue_pieces = [&](int kt, int stage, int j0, int j1) {
         char* st = smem + stage * T::STAGE_BYTES;
@@ -240,7 +248,9 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
             if (is_a) {
                 const int plane = (RPP % T::WAVES == 0) ? (j * T::WAVES) / RPP : q / RPP;
                 const int qi = q % RPP;
-                glds16(reinterpret_cast<const char*>(a_pl(kt, plane)) + qi * 1024 + a_lane, st + plane * T::A_PLANE_BYTES + qi * 1024);
+                const unsigned flip = T::F32 ? (unsigned)(qi & 1) * 64u : 0u;
+                glds16(reinterpret_cast<const char*>(a_pl(kt, plane)) + (size_t)(qi * RPQ) * lda_bytes + (a_lane ^ flip),
+                       st + plane * T::A_PLANE_BYTES + qi * 1024);
             } else {
                 const int qb = q - T::NA;
                 glds16(reinterpret_cast<const char*>(b_slab(kt)) + (size_t)(qb * KPP) * ldb * 4 + b_lane, st + T::A_BYTES + qb * 1024);
@@ -250,20 +260,25 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
     auto issue = [&](int kt, int stage) { issue_pieces(kt, stage, 0, G); };
 
     // ---- fragment read offsets (bytes inside a stage)
-    int a_off[TM][2];
+    // 16-bit planes: a lane's 8 k of (k16 half P) are ONE chunk; fp32: two consecutive chunks (NCH = 2)
+    constexpr int NCH = T::F32 ? 2 : 1;
+    int a_off[TM][2][NCH];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int row = (wm * TM + tm) * 32 + l31;
-        const int x = (row >> 2) & 3;
+        const int x = T::F32 ? (row >> 1) & 7 : (row >> 2) & 3;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) a_off[tm][s] = row * 64 + (((2 * s + half) ^ x) * 16);
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < NCH; ++e) a_off[tm][s][e] = row * T::ROW_BYTES + ((((2 * s + half) * NCH + e) ^ x) * 16);
     }
     const int b_off = T::A_BYTES + ((8 * half) * BN + wn * 32 + l31) * 4;
 
-    bf16x8 Af[2][TM][PA];     // [k16 half][tm][plane]
+    bf16x8 Af[2][TM][PA * NCH];   // [k16 half][tm][plane] (fp32: the lane's 8 k as two 16-byte chunks)
     float Br[2][8];           // raw B values of the k16 half
     float2 Bx[2][8];          // their per-row aux pairs (BX::ON)
     bf16x8 Bf[2][PA];         // split B planes
+    float Bv[2][8];           // fp32 mode: the (transformed) B values themselves
 
     auto read_b = [&](int stage, int slab, auto Pc) {
         constexpr int P = decltype(Pc)::value;
@@ -284,13 +299,16 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int pl = 0; pl < PA; ++pl) asm volatile("" : "+v"(Af[P][tm][pl]));
+                for (int pl = 0; pl < PA * NCH; ++pl) asm volatile("" : "+v"(Af[P][tm][pl]));
             return;
         }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int pl = 0; pl < PA; ++pl) Af[P][tm][pl] = *reinterpret_cast<const bf16x8*>(st + pl * T::A_PLANE_BYTES + a_off[tm][P]);
+            for (int pl = 0; pl < PA; ++pl)
+#pragma unroll
+                for (int e = 0; e < NCH; ++e)
+                    Af[P][tm][pl * NCH + e] = *reinterpret_cast<const bf16x8*>(st + pl * T::A_PLANE_BYTES + a_off[tm][P][e]);
     };
     auto split_part = [&](auto Ic, auto Pc) {
         constexpr int I = decltype(Ic)::value, P = decltype(Pc)::value;
@@ -298,7 +316,7 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = Br[P][j];
         if constexpr (Hooks::ENABLED) hooks.template bvals<I, P>(v);
-        if constexpr (ABL & 4) {
+        if constexpr ((ABL & 4) && !T::F32) {
 #pragma unroll
             for (int pl = 0; pl < PA; ++pl)
                 Bf[P][pl] = __builtin_bit_cast(bf16x8, ((vf4){v[pl], v[pl + 2], v[pl + 4], v[7 - pl]}));
@@ -308,7 +326,12 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = bx.apply(v[j], Bx[P][j]);
         }
-        split8<MODE>(v, Bf[P], T::ACT_SCALE);   // fp16 modes: scaled inside the split; bf16 modes: ACT_SCALE = 1
+        if constexpr (T::F32) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Bv[P][j] = v[j];
+        } else {
+            split8<MODE>(v, Bf[P], T::ACT_SCALE);   // fp16 modes: scaled inside the split; bf16 modes: ACT_SCALE = 1
+        }
     };
     auto mfma_part = [&](auto Ic, auto Pc, int tm0, int tm1) {
         constexpr int I = decltype(Ic)::value, P = decltype(Pc)::value;
@@ -328,7 +351,24 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
         }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
-            if (tm >= tm0 && tm < tm1) mfma_terms<MODE, Hooks::template fresh<I, P>()>(dst[tm], Af[P][tm], Bf[P]);
+            if (tm >= tm0 && tm < tm1) {
+                if constexpr (T::F32) {
+                    // eight exact fp32 products: lane half h multiplies k = 16 P + 8 h + j (the same k assignment for A and B)
+                    const vf4 a0 = __builtin_bit_cast(vf4, Af[P][tm][0]), a1 = __builtin_bit_cast(vf4, Af[P][tm][1]);
+                    f32x16 c = dst[tm];
+                    if constexpr (Hooks::template fresh<I, P>()) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], Bv[P][j], c, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], Bv[P][4 + j], c, 0, 0, 0);
+                    dst[tm] = c;
+                } else {
+                    mfma_terms<MODE, Hooks::template fresh<I, P>()>(dst[tm], Af[P][tm], Bf[P]);
+                }
+            }
     };
 
     // Schedule of step I (P0 / P1 = the two k16 halves of a slab; every fragment set is read half a step before its products):

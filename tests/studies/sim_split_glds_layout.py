@@ -80,7 +80,68 @@ def simulate(BM=128, WM=2, WN=4, PA=2, K=64, seed=0):
     return err
 
 
+def simulate_f32(BM=128, WM=4, WN=2, K=64, lda=512, seed=0):
+    """MODE 0: the A operand is the row-major fp32 matrix itself: 128-byte LDS rows, chunk c of row r at c ^ ((r >> 1) & 7)."""
+    rs = np.random.RandomState(seed)
+    TM, BN, WAVES = BM // WM // 32, 32 * WN, WM * WN
+    KT = K // 32
+    row0, col0, ldb = 128, 64, 640
+    A = rs.standard_normal((512, lda)).astype(np.float32)
+    B = rs.standard_normal((K, ldb)).astype(np.float32)
+    Af = A.reshape(-1)
+    NA, NB = BM * 128 // 1024, 32 * BN * 4 // 1024
+    G = (NA + NB) // WAVES
+    CPR, RPQ = 8, 8
+    LPR, KPP = BN // 4, 64 // (BN // 4)
+    C = np.zeros((BM, BN), np.float64)
+    for kt in range(KT):
+        ldsA = np.full(BM * 32, np.nan, np.float32)   # float index = byte / 4
+        ldsB = np.full(32 * BN, np.nan, np.float32)
+        for wave in range(WAVES):
+            for j in range(G):
+                q = j * WAVES + wave
+                for lane in range(64):
+                    if q < NA:
+                        qi = q
+                        a_lane = (lane // CPR) * (lda * 4) + (((lane % CPR) ^ ((lane >> 4) & 3)) * 16)
+                        flip = (qi & 1) * 64
+                        src_b = (row0 * lda + kt * 32) * 4 + qi * RPQ * lda * 4 + (a_lane ^ flip)
+                        dst_b = qi * 1024 + lane * 16
+                        ldsA[dst_b // 4:dst_b // 4 + 4] = Af[src_b // 4:src_b // 4 + 4]
+                    else:
+                        qb = q - NA
+                        b_lane = ((lane // LPR) * ldb + (lane % LPR) * 4)
+                        src = (kt * 32) * ldb + col0 + qb * KPP * ldb + b_lane
+                        dst = (qb * 1024 + lane * 16) // 4
+                        ldsB[dst:dst + 4] = B.reshape(-1)[src:src + 4]
+        assert not np.isnan(ldsA).any() and not np.isnan(ldsB).any()
+        for wave in range(WAVES):
+            wm, wn = wave // WN, wave % WN
+            for P in range(2):
+                for tm in range(TM):
+                    a_tile = np.zeros((32, 16)); b_tile = np.zeros((16, 32))
+                    for lane in range(64):
+                        half, l31 = lane >> 5, lane & 31
+                        row = (wm * TM + tm) * 32 + l31
+                        x = (row >> 1) & 7
+                        vals = []
+                        for e in range(2):
+                            off = row * 128 + ((((2 * P + half) * 2 + e) ^ x) * 16)
+                            vals += list(ldsA[off // 4:off // 4 + 4])
+                        a_tile[l31, 8 * half:8 * half + 8] = vals
+                        b_off = ((8 * half) * BN + wn * 32 + l31) * 4
+                        b_tile[8 * half:8 * half + 8, l31] = [ldsB[(b_off + (P * 16 + jj) * BN * 4) // 4] for jj in range(8)]
+                    r0 = (wm * TM + tm) * 32
+                    C[r0:r0 + 32, wn * 32:wn * 32 + 32] += a_tile @ b_tile
+    ref = A[row0:row0 + BM, :K].astype(np.float64) @ B[:, col0:col0 + BN].astype(np.float64)
+    return np.abs(C - ref).max()
+
+
 if __name__ == "__main__":
+    for cfg in (dict(lda=512), dict(lda=256), dict(lda=512, WM=2, WN=4)):
+        e = simulate_f32(**cfg)
+        print("fp32 mode", cfg, "max |C - A B| =", e)
+        assert e < 1e-9
     for cfg in (dict(BM=128, WM=2, WN=4, PA=2), dict(BM=128, WM=2, WN=2, PA=2), dict(BM=128, WM=2, WN=4, PA=3), dict(BM=128, WM=2, WN=2, PA=3)):
         e = simulate(**cfg)
         print(cfg, "max |C - A B| =", e)

@@ -44,7 +44,7 @@ def apply(spec):
         os.environ["GATSSPG_" + k] = v
 
 
-res = {s: {"kern": [], "lat": [], "thr": []} for s in a.settings}
+res = {s: {"kern": [], "lat": [], "thr": [], "par": None} for s in a.settings}
 for rnd in range(a.rounds + 1):
     for spec in a.settings:
         apply(spec)
@@ -68,9 +68,11 @@ for rnd in range(a.rounds + 1):
         thr = 2 * K * cfg["b"] / (time.perf_counter() - t0)
         if rnd:   # round 0 warms up
             res[spec]["kern"].append(kern); res[spec]["lat"].append(lat * 1e3 / cfg["b"]); res[spec]["thr"].append(thr)
-par = bench.golden_parity(r0, cfg)
-print(f"# {a.config}, kernel {a.kernel}, {a.rounds} interleaved rounds of {K} steps, one process; last setting's parity: {par and (par['argmax_flips'], par['max_abs_conf_err'])}")
-print(f"# {'setting':40s} {a.kernel + '_ms':>10s} {'ms/frame':>10s} {'single fps':>11s} {'fps 3 in flight':>16s}   (medians; min..max of ms/frame)")
+        else:
+            par = bench.golden_parity(r0, cfg)     # the setting's own parity number against the reference-run golden
+            res[spec]["par"] = par and (par["argmax_flips"], float(f"{par['max_abs_conf_err']:.3e}"))
+print(f"# {a.config}, kernel {a.kernel}, {a.rounds} interleaved rounds of {K} steps, one process")
+print(f"# {'setting':40s} {a.kernel + '_ms':>10s} {'ms/frame':>10s} {'single fps':>11s} {'fps 3 in flight':>16s}   (medians; min..max of ms/frame)   (arg-max flips, max |conf err|) vs the reference golden")
 for spec in a.settings:
     r = res[spec]
-    print(f"  {spec or 'defaults':40s} {np.median(r['kern']):10.5f} {np.median(r['lat']):10.4f} {1e3 / np.median(r['lat']):11.1f} {np.median(r['thr']):16.1f}   ({min(r['lat']):.4f}..{max(r['lat']):.4f})")
+    print(f"  {spec or 'defaults':40s} {np.median(r['kern']):10.5f} {np.median(r['lat']):10.4f} {1e3 / np.median(r['lat']):11.1f} {np.median(r['thr']):16.1f}   ({min(r['lat']):.4f}..{max(r['lat']):.4f})   {r['par']}")
