@@ -62,7 +62,24 @@ using QkvSpTile = SpTile<128, 2, 2, 2, MODE>;
 // workgroups per CU, <= 128 registers), three stages of 24 KiB
 using Fp32SpTile = SpTile<128, 4, 2, 3, 0>;
 
-template <class T, int SCHED = 0>
+// A plain output tile straight from the accumulators: in the 32 x 32 C layout a lane's 16 values of one product sit in ONE column
+// (lane & 31) and 16 rows, so each dword store instruction covers two rows x 32 consecutive columns = two full 128-byte lines --
+// no LDS round trip, no barrier in front of the stores (store_tile_via_lds: 32 scalar LDS writes, a barrier, 8 row reads, 8 16-byte stores).
+template <class T, class F>
+__device__ __forceinline__ void store_tile_direct(const f32x16 (&acc)[T::TM][T::TN], float* dst, int ld, F f) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    float* d = dst + wn * 32 + l31;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);
+            d[(size_t)row * ld] = f(row, acc[tm][0][r]);
+        }
+}
+
+template <class T, int SCHED = 0, int EPI = 0>
 __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : 3)) void qkv_kv_sp_kernel(const float* __restrict__ sc, const float* __restrict__ bqkv,
                                                                 const unsigned short* __restrict__ P0, const unsigned short* __restrict__ P1,
                                                                 const unsigned short* __restrict__ P2, const float* __restrict__ Z,
@@ -97,7 +114,8 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : 3)) void qkv_kv_sp_kernel
         for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][0][r] = elu1_select(fmaf(acc[tm][0][r], inv, bias[tm][r])) + 1.f;
-        store_tile_via_lds<T>(acc, smem, Qbuf + (size_t)rt * 128 * ld + c0, ld, [](int, float v) { return v; });
+        if constexpr (EPI == 1) store_tile_direct<T>(acc, Qbuf + (size_t)rt * 128 * ld + c0, ld, [](int, float v) { return v; });
+        else store_tile_via_lds<T>(acc, smem, Qbuf + (size_t)rt * 128 * ld + c0, ld, [](int, float v) { return v; });
         return;
     }
     // ---- K_h / V_h tile -> LDS -> KV partial (second MFMA pass, fp32: exact like the fp32 kernel's)
@@ -219,7 +237,7 @@ using Mlp0SpTileN2 = SpTile<128, 2, 2, 2, MODE>;  // the same on a two-stage rin
 template <int MODE>
 using Mlp0SpTileT = SpTile<128, 1, 4, 3, MODE>;   // 128 x 128 on 4 waves, 128 x 32 per wave (one wave per SIMD, every B value split once)
 
-template <class T, int ABL = 0, int SCHED = 0>
+template <class T, int ABL = 0, int SCHED = 0, int EPI = 0>
 __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::TM == 4 ? 1 : (T::WAVES == 4 && T::NST == 2) ? 3 : 2)) void mlp0_sp_kernel(const float* __restrict__ sc, const float* __restrict__ b0,
                                                               const unsigned short* __restrict__ P0, const unsigned short* __restrict__ P1,
                                                               const unsigned short* __restrict__ P2, const float* __restrict__ Z,
@@ -297,7 +315,7 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::TM == 4 ? 1 : (T::WAVE
     if (SP_TRACE_ON(trace)) tr.t[10] = __builtin_readcyclecounter();   // last fold + bias + tile written to LDS
     __syncthreads();
     if (SP_TRACE_ON(trace)) tr.t[11] = __builtin_readcyclecounter();
-    {   // per-row (sum, pivot-shifted centred sum of squares) of the real columns of each 64-column tile (mlp0_kernel's form)
+    auto tile_statistics = [&]() {   // per-row (sum, pivot-shifted centred sum of squares) of the real columns of each 64-column tile (mlp0_kernel's form)
         constexpr int LPR = T::THREADS / T::BM;    // lanes per row
         constexpr int LPS = LPR / TPW;             // lanes per (row, 64-column tile)
         constexpr int CPL = MLP0_BN / LPS;         // columns per lane
@@ -331,19 +349,29 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::TM == 4 ? 1 : (T::WAVE
             stat_partial_store(statpart + (t64 * 2 + 0) * 512 + rt * T::BM + row, nv * pivot + s1);                      // sum
             stat_partial_store(statpart + (t64 * 2 + 1) * 512 + rt * T::BM + row, nv > 0.f ? s2 - s1 * s1 / nv : 0.f);   // M2
         }
-    }
-    // the partial stores above go first; the tile's own stores follow them and may still be in flight when the ticket is drawn
-    asm volatile("" ::: "memory");
-    // then the tile leaves through LDS as 16-byte stores: 16 lanes cover one 256-byte row segment
+    };
+    // the tile leaves through LDS as 16-byte stores: 16 lanes cover one 256-byte row segment
+    auto tile_stores = [&]() {
 #pragma unroll
-    for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
-        const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
-        const vf4 v = *reinterpret_cast<const vf4*>(Tl + row * TS + c4);
-        if constexpr (ABL & 16) {   // timing only: no global stores of the tile
-            if (v[0] == 123.456f) U[0] = v[1];
-        } else {
-            *reinterpret_cast<vf4*>(U + (size_t)(rt * T::BM + row) * ld + c0 + c4) = v;
+        for (int idx = tid; idx < T::BM * (T::BN / 4); idx += T::THREADS) {
+            const int row = idx / (T::BN / 4), c4 = (idx % (T::BN / 4)) * 4;
+            const vf4 v = *reinterpret_cast<const vf4*>(Tl + row * TS + c4);
+            if constexpr (ABL & 16) {   // timing only: no global stores of the tile
+                if (v[0] == 123.456f) U[0] = v[1];
+            } else {
+                *reinterpret_cast<vf4*>(U + (size_t)(rt * T::BM + row) * ld + c0 + c4) = v;
+            }
         }
+    };
+    if constexpr (EPI == 1) {   // (stat_final launch only) the tile's stores drain while the statistics are summed
+        tile_stores();
+        asm volatile("" ::: "memory");
+        tile_statistics();
+    } else {
+        // the partial stores go first; the tile's own stores follow them and may still be in flight when the ticket is drawn
+        tile_statistics();
+        asm volatile("" ::: "memory");
+        tile_stores();
     }
     if (SP_TRACE_ON(trace)) tr.t[12] = __builtin_readcyclecounter();   // tile stores issued
     constexpr int TILE_STORES = T::BM * (T::BN / 4) / T::THREADS;   // per thread, behind its partial stores
@@ -389,7 +417,7 @@ struct InstNormBx {
     __device__ __forceinline__ float apply(float v, float2 ms) const { return fmaxf((v - ms.x) * ms.y, 0.f); }
 };
 
-template <class T, int SCHED = 0>
+template <class T, int SCHED = 0, int EPI = 0>
 __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::NST == 2 ? 3 : 2)) void mlp3_sp_kernel(const float* __restrict__ sc, const float* __restrict__ b3,
                                                               const unsigned short* __restrict__ P0, const unsigned short* __restrict__ P1,
                                                               const unsigned short* __restrict__ P2, const float* __restrict__ U,
@@ -434,7 +462,8 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::NST == 2 ? 3 : 2)) voi
     };
     gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), SpPlainHooks<false>, InstNormBx, 0, SCHED, decltype(pre)>(
         reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, bx, nullptr, pre, false, T::F32 ? 512 * 4 : 64);
-    store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [inv](int, float v) { return v * inv; });
+    if constexpr (EPI == 1) store_tile_direct<T>(acc, Z + (size_t)rt * T::BM * ld + c0, ld, [inv](int, float v) { return v * inv; });
+    else store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [inv](int, float v) { return v * inv; });
 }
 
 // =====================================================================================================
@@ -553,6 +582,8 @@ static PlaneSet planes(const unsigned short* wb, int prec, size_t hi, size_t lo,
 }
 
 // schedule of the split loop in the fp16 modes: 2 (default) = DMA requests spread over the step, 0 = in one burst behind the barrier (gemm_split_glds.h)
+// epilogue of the plain tiles: bit 0 the Q tiles of qkv_kv, bit 1 mlp3 store straight from the accumulators (store_tile_direct)
+static int sp_direct_store() { return tuning_knob("SP_DIRECT_STORE", 3); }   // 3: +0.5 % per frame (profiles/r04_ab_live_direct_store.txt); bit 2 = mlp0 stores in front of its statistics (neutral)
 static int sp_sched() {
     // 2 measured 1.0-1.4 % faster per frame than 0 in interleaved single-process A/B runs (profiles/r04_ab_live_*.txt)
     return tuning_knob("SP_SCHED", 2);   // (read per launch: tools/ab_live.py flips it inside one process)
@@ -564,6 +595,12 @@ static void launch_qkv_sp_t(const float* sc, const float* bqkv, const unsigned s
     const PlaneSet p = planes(wb, MODE, AttnWB::QKV_HI, AttnWB::QKV_LO, AttnWB::QKV_LO2, AttnWB::QKV_H16, AttnWB::QKV_L16);
     if constexpr (MODE >= 3) {
         if (sp_sched() == 2) {
+            if (sp_direct_store() & 1) {
+                allow_big_lds_sp<qkv_kv_sp_kernel<T, 2, 1>>();
+                GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 2, 1>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s,
+                               sc, bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
+                return;
+            }
             allow_big_lds_sp<qkv_kv_sp_kernel<T, 2>>();
             GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 2>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s,
                            sc, bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
@@ -606,9 +643,17 @@ void launch_qkv_kv_sp(const float* sc, const float* bqkv, const unsigned short* 
 
 template <class T, int ABL = 0, int SCHED = 0>
 static void launch_mlp0_sp_t(const float* sc, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    allow_big_lds_sp<mlp0_sp_kernel<T, ABL, SCHED>>();
     const PlaneSet p = planes(wb, T::MODE, AttnWB::W0_HI, AttnWB::W0_LO, AttnWB::W0_LO2, AttnWB::W0_H16, AttnWB::W0_L16);
     const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
+    if constexpr (ABL == 0 && SCHED == 2) {
+        if ((sp_direct_store() & 4) && !stat_fused()) {   // tile stores in front of the statistics
+            allow_big_lds_sp<mlp0_sp_kernel<T, ABL, SCHED, 1>>();
+            GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_sp_kernel<T, ABL, SCHED, 1>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 1024, s, sc,
+                           b0, p.p0, p.p1, p.p2, w.Z, w.Q, w.Mpl, w.ksumT, w.zsc, w.U, w.statpart, w.stats, nullptr, w.L, g_trace);
+            return;
+        }
+    }
+    allow_big_lds_sp<mlp0_sp_kernel<T, ABL, SCHED>>();
     GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_sp_kernel<T, ABL, SCHED>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 1024, s, sc, b0,
                    p.p0, p.p1, p.p2, w.Z, w.Q, w.Mpl, w.ksumT, w.zsc, w.U, w.statpart, w.stats, stat_fused() ? w.statcnt : nullptr, w.L, g_trace);
 }
@@ -644,7 +689,7 @@ static void launch_mlp0_sp_m(const float* sc, const float* b0, const unsigned sh
 #endif
     const bool wide = active_tiles(w.L) / 2 >= wide_min && active_tiles(w.L) / 2 <= wide_max;
     if constexpr (MODE == 4) {
-        if (tuning_knob("SP_NST2", 0) & 1) return launch_mlp0_sp_t<Mlp0SpTileN2<MODE>, 0, 2>(sc, b0, wb, w, s, hk);   // three workgroups per CU
+        if (tuning_knob("SP_NST2", -1) > 0 && (tuning_knob("SP_NST2", -1) & 1)) return launch_mlp0_sp_t<Mlp0SpTileN2<MODE>, 0, 2>(sc, b0, wb, w, s, hk);   // three workgroups per CU
     }
     if constexpr (MODE >= 3) {
         if (sp_sched() == 2) {
@@ -670,9 +715,18 @@ static void launch_mlp3_sp_t(const float* sc, const float* b3, const unsigned sh
     using T = Mlp3SpTile<MODE>;
     const PlaneSet p = planes(wb, MODE, AttnWB::W3_HI, AttnWB::W3_LO, AttnWB::W3_LO2, AttnWB::W3_H16, AttnWB::W3_L16);
     const int NT = active_tiles(w.L) / (T::BN / 64);
-    if constexpr (MODE == 4) {
-        if (tuning_knob("SP_NST2", 0) & 2) {
+    if constexpr (MODE >= 3) {
+        // more than one round of the three-stage ring's two workgroups per CU (batched frames, N_3D = 20000): the two-stage ring's three
+        // per CU turn 1.46 rounds into one at 8 frames per step (fp16x4-b8: 0.565 vs 0.571 ms per frame, profiles/r04_ab_live_b8_tiles.txt)
+        const int nst2 = tuning_knob("SP_NST2", -1);
+        if (nst2 >= 0 ? (nst2 & 2) != 0 : (256 / Mlp3SpTile2<MODE>::BM) * NT > 512) {
             using T2 = Mlp3SpTile2<MODE>;
+            if (sp_direct_store() & 2) {
+                allow_big_lds_sp<mlp3_sp_kernel<T2, 2, 1>>();
+                GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T2, 2, 1>), dim3(xcd_grid(256 / T2::BM, NT)), dim3(T2::THREADS), (size_t)T2::RING_BYTES + 4096, s,
+                               sc, b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
+                return;
+            }
             allow_big_lds_sp<mlp3_sp_kernel<T2, 2>>();
             GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T2, 2>), dim3(xcd_grid(256 / T2::BM, NT)), dim3(T2::THREADS), (size_t)T2::RING_BYTES + 4096, s,
                            sc, b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
@@ -681,6 +735,12 @@ static void launch_mlp3_sp_t(const float* sc, const float* b3, const unsigned sh
     }
     if constexpr (MODE >= 3) {
         if (sp_sched() == 2) {
+            if (sp_direct_store() & 2) {
+                allow_big_lds_sp<mlp3_sp_kernel<T, 2, 1>>();
+                GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, 2, 1>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc,
+                               b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
+                return;
+            }
             allow_big_lds_sp<mlp3_sp_kernel<T, 2>>();
             GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, 2>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc,
                            b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
