@@ -235,6 +235,8 @@ using Mlp0SpTileN = SpTile<128, 2, 2, 3, MODE>;   // 128 x 64 on 4 waves: twice 
 template <int MODE>
 using Mlp0SpTileN2 = SpTile<128, 2, 2, 2, MODE>;  // the same on a two-stage ring (49 KiB): three workgroups per CU when the registers allow (<= 168)
 template <int MODE>
+using Mlp0SpTileW4 = SpTile<128, 2, 4, 4, MODE>;  // the 8-wave tile on a FOUR-stage ring (128 KiB): a slab has two and a half steps to land
+template <int MODE>
 using Mlp0SpTileT = SpTile<128, 1, 4, 3, MODE>;   // 128 x 128 on 4 waves, 128 x 32 per wave (one wave per SIMD, every B value split once)
 
 template <class T, int ABL = 0, int SCHED = 0, int EPI = 0>
@@ -497,7 +499,9 @@ __global__ __launch_bounds__(T::THREADS, 3) void score_exp_sp_kernel(const unsig
     auto bsl = [&](int kt) { return Bp + (size_t)kt * BK * ld; };
     SpPlainHooks<true> hooks;
     SpNoBx nobx;
-    gemm_mainloop_sp<T, D / BK>(reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx);
+    constexpr int SS = T::F16 ? 4 : 0;   // fp16x4: the slot schedule (gemm_split_glds.h); bf16x6: the plain one
+    gemm_mainloop_sp<T, D / BK, decltype(apl), decltype(bsl), SpPlainHooks<true>, SpNoBx, 0, SS>(reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld,
+                                                                                                hooks, nobx);
     const float inv = T::F16 ? 1.f / (T::ACT_SCALE * T::ACT_SCALE) : 1.f;   // both operands carry the scale
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
@@ -581,12 +585,13 @@ static PlaneSet planes(const unsigned short* wb, int prec, size_t hi, size_t lo,
     return {wb + hi, wb + lo, wb + lo2};
 }
 
-// schedule of the split loop in the fp16 modes: 2 (default) = DMA requests spread over the step, 0 = in one burst behind the barrier (gemm_split_glds.h)
-// epilogue of the plain tiles: bit 0 the Q tiles of qkv_kv, bit 1 mlp3 store straight from the accumulators (store_tile_direct)
+// schedule of the split loop in the fp16 modes (gemm_split_glds.h): 4 (default) = the slot schedule -- every MFMA of a step carries its share of the
+// step's VALU work, DMA requests and LDS reads, fenced slot by slot; 3 = the same with the next slab's reads in two bursts; 2 = DMA requests spread over
+// the step, split work left to hipcc's grouping; 0 = DMA requests in one burst behind the barrier; 1 = ping-pong wave groups.
 static int sp_direct_store() { return tuning_knob("SP_DIRECT_STORE", 3); }   // 3: +0.5 % per frame (profiles/r04_ab_live_direct_store.txt); bit 2 = mlp0 stores in front of its statistics (neutral)
 static int sp_sched() {
-    // 2 measured 1.0-1.4 % faster per frame than 0 in interleaved single-process A/B runs (profiles/r04_ab_live_*.txt)
-    return tuning_knob("SP_SCHED", 2);   // (read per launch: tools/ab_live.py flips it inside one process)
+    // interleaved single-process A/B runs (profiles/r04_ab_live_*.txt): 2 is 1.0-1.4 % faster per frame than 0, 3 another 1.0-1.6 %, 4 another 0.4 %
+    return tuning_knob("SP_SCHED", 4);   // (read per launch: tools/ab_live.py flips it inside one process)
 }
 
 template <int MODE>
@@ -594,6 +599,18 @@ static void launch_qkv_sp_t(const float* sc, const float* bqkv, const unsigned s
     using T = QkvSpTile<MODE>;
     const PlaneSet p = planes(wb, MODE, AttnWB::QKV_HI, AttnWB::QKV_LO, AttnWB::QKV_LO2, AttnWB::QKV_H16, AttnWB::QKV_L16);
     if constexpr (MODE >= 3) {
+        if (sp_sched() == 3) {   // the slot schedule (every MFMA carries its share of the step's VALU work), direct Q stores
+            allow_big_lds_sp<qkv_kv_sp_kernel<T, 3, 1>>();
+            GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 3, 1>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s,
+                           sc, bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
+            return;
+        }
+        if (sp_sched() == 4) {
+            allow_big_lds_sp<qkv_kv_sp_kernel<T, 4, 1>>();
+            GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 4, 1>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s,
+                           sc, bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
+            return;
+        }
         if (sp_sched() == 2) {
             if (sp_direct_store() & 1) {
                 allow_big_lds_sp<qkv_kv_sp_kernel<T, 2, 1>>();
@@ -692,6 +709,17 @@ static void launch_mlp0_sp_m(const float* sc, const float* b0, const unsigned sh
         if (tuning_knob("SP_NST2", -1) > 0 && (tuning_knob("SP_NST2", -1) & 1)) return launch_mlp0_sp_t<Mlp0SpTileN2<MODE>, 0, 2>(sc, b0, wb, w, s, hk);   // three workgroups per CU
     }
     if constexpr (MODE >= 3) {
+        if (sp_sched() == 3) {
+            if (wide && (tuning_knob("SP_NST4", 0) & 1)) return launch_mlp0_sp_t<Mlp0SpTileW4<MODE>, 0, 3>(sc, b0, wb, w, s, hk);
+            if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 3>(sc, b0, wb, w, s, hk);
+            else launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 3>(sc, b0, wb, w, s, hk);
+            return;
+        }
+        if (sp_sched() == 4) {
+            if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 4>(sc, b0, wb, w, s, hk);
+            else launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 4>(sc, b0, wb, w, s, hk);
+            return;
+        }
         if (sp_sched() == 2) {
             if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 2>(sc, b0, wb, w, s, hk);
             else launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 2>(sc, b0, wb, w, s, hk);
@@ -721,6 +749,18 @@ static void launch_mlp3_sp_t(const float* sc, const float* b3, const unsigned sh
         const int nst2 = tuning_knob("SP_NST2", -1);
         if (nst2 >= 0 ? (nst2 & 2) != 0 : (256 / Mlp3SpTile2<MODE>::BM) * NT > 512) {
             using T2 = Mlp3SpTile2<MODE>;
+            if (sp_sched() == 3) {
+                allow_big_lds_sp<mlp3_sp_kernel<T2, 3, 1>>();
+                GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T2, 3, 1>), dim3(xcd_grid(256 / T2::BM, NT)), dim3(T2::THREADS), (size_t)T2::RING_BYTES + 4096, s,
+                               sc, b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
+                return;
+            }
+            if (sp_sched() == 4) {
+                allow_big_lds_sp<mlp3_sp_kernel<T2, 4, 1>>();
+                GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T2, 4, 1>), dim3(xcd_grid(256 / T2::BM, NT)), dim3(T2::THREADS), (size_t)T2::RING_BYTES + 4096, s,
+                               sc, b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
+                return;
+            }
             if (sp_direct_store() & 2) {
                 allow_big_lds_sp<mlp3_sp_kernel<T2, 2, 1>>();
                 GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T2, 2, 1>), dim3(xcd_grid(256 / T2::BM, NT)), dim3(T2::THREADS), (size_t)T2::RING_BYTES + 4096, s,
@@ -734,6 +774,18 @@ static void launch_mlp3_sp_t(const float* sc, const float* b3, const unsigned sh
         }
     }
     if constexpr (MODE >= 3) {
+        if (sp_sched() == 3) {
+            allow_big_lds_sp<mlp3_sp_kernel<T, 3, 1>>();
+            GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, 3, 1>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc,
+                           b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
+            return;
+        }
+        if (sp_sched() == 4) {
+            allow_big_lds_sp<mlp3_sp_kernel<T, 4, 1>>();
+            GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, 4, 1>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc,
+                           b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
+            return;
+        }
         if (sp_sched() == 2) {
             if (sp_direct_store() & 2) {
                 allow_big_lds_sp<mlp3_sp_kernel<T, 2, 1>>();

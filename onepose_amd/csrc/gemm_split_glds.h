@@ -83,7 +83,7 @@ struct SpTile {
     static constexpr float ACT_SCALE = F16 ? (float)(1 << ASL_) : 1.f;
     static_assert(TM >= 1 && BM % (32 * WM) == 0, "wave tile");
     static_assert(BM % 16 == 0 && (NA + NB) % WAVES == 0, "DMA pieces must divide evenly over the waves");
-    static_assert(NST == 2 || NST == 3, "two or three stages");
+    static_assert(NST >= 2 && NST <= 4, "two to four stages");
     static_assert(BN == 64 || BN == 128, "a B piece is 2 or 4 whole k rows");
 };
 
@@ -433,7 +433,7 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
         // the workgroup hit the CU's DMA path at once: ~140 cycles per piece in the trace): slot 0 behind the barrier, slot 1 between
         // the two halves of products (I, P1), slot 2 behind them, slot 3 (three-stage rings only: the slab has a whole further step to
         // land) inside the next step's first product group.  The raw B values of (I + 1, P1) are read between the halves as well.
-        constexpr int NSLOT = NST == 3 ? 4 : 3;
+        constexpr int NSLOT = NST >= 3 ? 4 : 3;
         constexpr int E0 = (G + NSLOT - 1) / NSLOT, E1 = E0 + (G - E0 + NSLOT - 2) / (NSLOT - 1);
         constexpr int E2 = NSLOT == 3 ? G : E1 + (G - E1 + 1) / 2;
         read_b(0, 0, IC<0>{});
@@ -487,6 +487,123 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
                 __builtin_amdgcn_sched_barrier(0);
                 stamp(I, 7);
             }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(-1, 8);
+        wait_dma_barrier<0>();
+        return;
+    }
+    if constexpr (SCHED == 3 || SCHED == 4) {
+        // SCHED 2's data flow with the VALU work of a step pinned UNDER its MFMAs, one slot per MFMA (tools/microbench/mfma_valu_overlap.hip:
+        // a wave that follows every 32-cycle MFMA with up to ~5 VALU instructions runs at the matrix pipe's rate, alone or with a partner
+        // wave on its SIMD; 16 MFMAs followed by 80 VALU cost the sum -- and the per-step barrier keeps the two waves of a SIMD in phase, so
+        // a partner cannot fill the gap).  hipcc left to itself keeps the four term products of an accumulator back to back and packs a
+        // half step's 20-28 split instructions under four of its eight MFMAs; here every slot is fenced:
+        //   products (I, P0) m = 0 .. HM-1 : pair q of split (I, P1) under m = q HM/4 (hooks: the raw-value dot under m = 0, the head fold under m = HM/2)
+        //   counted wait + barrier(I)
+        //   products (I, P1) m = 0 .. HM-1 : DMA pieces + reads of slab I + 1 under m = 0, HM/4, HM-2; pair q of split (I + 1, P0) under m = HM-4+q
+        static_assert(!T::F32 && MODE >= 3, "the slot schedule is written for the two-plane fp16 modes");
+        constexpr int NT = MODE == 4 ? 4 : 3, HM = TM * NT, QA = HM / 4, S0 = HM - 4, PP = 1;
+        constexpr bool SPREAD = SCHED == 4;   // the reads of slab I + 1 one group per slot instead of two groups under product 1 of (I, P1)
+        static_assert(QA >= 1 && S0 >= 0, "four pairs per half step");
+        constexpr int NSLOT = NST >= 3 ? 4 : 3;
+        constexpr int E0 = (G + NSLOT - 1) / NSLOT, E1 = E0 + (G - E0 + NSLOT - 2) / (NSLOT - 1);
+        constexpr int E2 = NSLOT == 3 ? G : E1 + (G - E1 + 1) / 2;
+        unsigned Bw[2][2][4];   // [k16 half][plane][dword]: the split B planes, written pair by pair
+        auto one = [&](auto Ic, auto Pc, auto Mc) {
+            constexpr int I = decltype(Ic)::value, P = decltype(Pc)::value, M = decltype(Mc)::value, tm = M / NT, t = M % NT;
+            f32x16(&dst)[TM] = hooks.template target<I, TM>(acc);
+            // term order of mfma_terms (small terms first): fp16x4 (a1 b1) (a1 b0) (a0 b1) (a0 b0); fp16x3 (a1 b0) (a0 b1) (a0 b0)
+            constexpr int ap = MODE == 4 ? (t < 2 ? 1 : 0) : (t == 0 ? 1 : 0);
+            constexpr int bp = MODE == 4 ? ((t & 1) ? 0 : 1) : (t == 1 ? 1 : 0);
+            const f16x8 a = __builtin_bit_cast(f16x8, Af[P][tm][ap]);
+            const f16x8 b = __builtin_bit_cast(f16x8, ((u32x4){Bw[P][bp][0], Bw[P][bp][1], Bw[P][bp][2], Bw[P][bp][3]}));
+            if constexpr (t == 0 && Hooks::template fresh<I, P>()) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                dst[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, z, 0, 0, 0);
+            } else {
+                dst[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, dst[tm], 0, 0, 0);
+            }
+        };
+        auto pair = [&](auto Pc, auto Qc) {
+            constexpr int P = decltype(Pc)::value, q = decltype(Qc)::value;
+            float a = Br[P][2 * q], b = Br[P][2 * q + 1];
+            if constexpr (BX::ON) {
+                a = bx.apply(a, Bx[P][2 * q]);
+                b = bx.apply(b, Bx[P][2 * q + 1]);
+            }
+            if (T::ACT_SCALE != 1.f) fp16_split2_scaled(a, b, T::ACT_SCALE, Bw[P][0][q], Bw[P][1][q]);
+            else fp16_split2_mix(a, b, Bw[P][0][q], Bw[P][1][q]);
+        };
+        read_b(0, 0, IC<0>{});
+        read_b(0, 0, IC<1>{});
+        read_a(0, IC<0>{});
+        read_a(0, IC<1>{});
+        if constexpr (Hooks::ENABLED) hooks.template bvals<0, 0>(Br[0]);
+        static_for<0, 4>([&](auto Qc) { pair(IC<0>{}, Qc); });
+        stamp(-1, 0);
+        static_for<0, KT>([&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (I == SP_TRACE_STEP) stamp(I, 1);   // (profiling builds) 1 step start, 2 / 3 behind the first / second half of products (I, P0)
+            static_for<0, HM>([&](auto Mc) {
+                constexpr int M = decltype(Mc)::value;
+                if constexpr (I == SP_TRACE_STEP && M == HM / 2) stamp(I, 2);
+                one(Ic, IC<0>{}, Mc);
+                if constexpr (M == 0 && Hooks::ENABLED) hooks.template bvals<I, 1>(Br[1]);
+                if constexpr (PP == 1) {
+                    if constexpr (M % QA == 0 && M / QA < 4) pair(IC<1>{}, IC<M / QA>{});
+                } else {   // two pairs per slot: their instructions fill each other's hazard slots (three s_nop per lone pair)
+                    if constexpr (M % (2 * QA) == 0 && M / (2 * QA) < 2) {
+                        pair(IC<1>{}, IC<2 * (M / (2 * QA))>{});
+                        pair(IC<1>{}, IC<2 * (M / (2 * QA)) + 1>{});
+                    }
+                }
+                if constexpr (M == 1 && E2 < G && I >= 1 && I - 1 + NST < KT && !(ABL & 1)) issue_pieces(I - 1 + NST, (I - 1) % NST, E2, G);
+                if constexpr (M == HM / 2 && Hooks::ENABLED) hooks.template in_step<I, TM>(acc);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (I == SP_TRACE_STEP) stamp(I, 3);
+            if constexpr (I + 1 < KT) {
+                constexpr int LATER = (I + NST - 1 < KT - 1 ? I + NST - 1 : KT - 1) - (I + 1);
+                wait_dma_barrier<LATER * G>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (I == SP_TRACE_STEP) stamp(I, 4);   // 4 behind the barrier, 5 / 6 behind products 2 / 4 of (I, P1), 7 behind the last
+            static_for<0, HM>([&](auto Mc) {
+                constexpr int M = decltype(Mc)::value;
+                if constexpr (I == SP_TRACE_STEP && M == 2) stamp(I, 5);
+                if constexpr (I == SP_TRACE_STEP && M == 4) stamp(I, 6);
+                if constexpr (I + 1 < KT) {
+                    if constexpr (M == 0) {
+                        read_b((I + 1) % NST, I + 1, IC<0>{});
+                        if constexpr (!SPREAD) read_a((I + 1) % NST, IC<0>{});
+                        if constexpr (I + NST < KT && !(ABL & 1)) issue_pieces(I + NST, I % NST, 0, E0);
+                    }
+                    if constexpr (SPREAD && M == 1) read_a((I + 1) % NST, IC<0>{});
+                    if constexpr (M == (SPREAD ? 2 : QA)) {
+                        if constexpr (I + NST < KT && !(ABL & 1)) issue_pieces(I + NST, I % NST, E0, E1);
+                        if constexpr (!SPREAD) read_b((I + 1) % NST, I + 1, IC<1>{});
+                    }
+                    if constexpr (SPREAD && M == 3) read_b((I + 1) % NST, I + 1, IC<1>{});
+                }
+                one(Ic, IC<1>{}, Mc);
+                if constexpr (I + 1 < KT) {
+                    if constexpr (M == S0 && Hooks::ENABLED) hooks.template bvals<I + 1, 0>(Br[0]);
+                    if constexpr (PP == 1) {
+                        if constexpr (M >= S0) pair(IC<0>{}, IC<M - S0>{});
+                    } else if constexpr (M == S0 || M == S0 + 2) {
+                        pair(IC<0>{}, IC<M - S0>{});
+                        pair(IC<0>{}, IC<M - S0 + 1>{});
+                    }
+                    if constexpr (M == HM - 2 && I + NST < KT && !(ABL & 1)) issue_pieces(I + NST, I % NST, E1, E2);
+                    if constexpr (M == HM - 1) read_a((I + 1) % NST, IC<1>{});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (I == SP_TRACE_STEP) stamp(I, 7);
         });
         __builtin_amdgcn_sched_barrier(0);
         stamp(-1, 8);

@@ -32,6 +32,10 @@ print(f"cycles (s_memtime ticks, shader clock): prologue {med(pro - ent):.0f}  l
       f"epilogue {med(end - end_loop):.0f}  whole wave {med(end - ent):.0f}  (p10 / p90 whole: {np.percentile(end - ent, 10):.0f} / {np.percentile(end - ent, 90):.0f})")
 names = ["products (I,P0) + split (I,P1) + hooks", "counted wait + barrier", "DMA requests + raw B reads + A reads", "products (I,P1) first half",
          "products (I,P1) second half + split (I+1,P0)", "A reads (I+1,P1)"]
+if os.environ.get("GATSSPG_SP_SCHED") in ("3", "4"):   # the slot schedule: stamps at MFMA counts
+    names = ["products (I,P0) 1..4 (+ 2 pairs of split (I,P1), hooks)", "products (I,P0) 5..8 (+ 2 pairs, head fold)", "counted wait + barrier",
+             "products (I,P1) 1..2 (+ DMA pieces, B / A reads of slab I+1)", "products (I,P1) 3..4 (+ DMA piece, B reads)",
+             "products (I,P1) 5..8 (+ 4 pairs of split (I+1,P0), DMA piece, A reads)"]
 seg = t[:, 4:11].astype(np.int64)
 for k, nme in enumerate(names):
     d = seg[:, k + 1] - seg[:, k]
