@@ -23,8 +23,8 @@ cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 50 --warmup 5 --reps 1 --no-cpu-baseline --no-side-arithmetics"
 rocprofv3 --kernel-trace --stats -d $O/prof_s1 -o r -- $B --streams 1 > $O/prof_s1.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_s3 -o r -- $B --streams 3 > $O/prof_s3.log 2>&1
-for c in fp16x4 bf16x6 fp16x3 real fp16x4-stress-b4; do
-  st=50; [[ $c == *stress* ]] && st=10
+for c in fp16x4 fp16x4-b8 bf16x6 fp16x3 real fp16x4-stress-b4; do
+  st=50; [[ $c == *stress* || $c == *b8* ]] && st=10
   rocprofv3 --kernel-trace --stats -d $O/prof_$c -o r -- python $R/bench.py --steps $st --warmup 5 --reps 1 --no-cpu-baseline --no-side-arithmetics --streams 1 --config $c > $O/prof_$c.log 2>&1
 done
 P="python $R/bench.py --steps 6 --warmup 2 --reps 1 --streams 1 --no-cpu-baseline --no-side-arithmetics"
@@ -32,7 +32,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_fp16x4 -o r -- $P --co
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_fp16x4 -o r -- $P --config fp16x4 > $O/pmc_write_fp16x4.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $O/pmc_sq_fp16x4 -o r -- $P --config fp16x4 > $O/pmc_sq_fp16x4.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES -d $O/pmc_sq -o r -- $P > $O/pmc_sq.log 2>&1
-for d in prof_s1 prof_s3 prof_fp16x4 prof_bf16x6 prof_fp16x3 prof_real prof_fp16x4-stress-b4; do python $R/tools/rocpd_stats.py $(find $O/$d -name "*.db" | head -1) > $O/kernel_stats_$d.txt 2>&1; done
+for d in prof_s1 prof_s3 prof_fp16x4 prof_fp16x4-b8 prof_bf16x6 prof_fp16x3 prof_real prof_fp16x4-stress-b4; do python $R/tools/rocpd_stats.py $(find $O/$d -name "*.db" | head -1) > $O/kernel_stats_$d.txt 2>&1; done
 for d in pmc_fetch_fp16x4 pmc_write_fp16x4 pmc_sq_fp16x4 pmc_sq; do python $R/tools/rocpd_pmc.py $(find $O/$d -name "*.db" | head -1) > $O/$d.txt 2>&1; done
 find $O -name "*.db" -delete
 ls $O | head -80
