@@ -5,6 +5,8 @@ size -- through size-independent properties.
 Tolerances (north_star): conf within 1e-4 abs of the reference fp32 forward; match indices bit-exact.
 Per-stage tensors are checked tighter (they are O(0.1) magnitudes): atol 2e-5.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -798,3 +800,57 @@ def test_unknown_flag_bits_are_refused():
                              conf.data_ptr(), m0.data_ptr(), m1.data_ptr(), s0.data_ptr(), s1.data_ptr(), ws.data_ptr(), ws.numel(),
                              torch.cuda.current_stream().cuda_stream)
     assert rc != 0 and b"exclusive" in lib.gatsspg_last_error()
+
+
+_SCHEDULE_PROBE = r"""
+import hashlib, json, os, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from onepose_amd import _native, build_ext
+_native.LIB_PATH = build_ext.tuning_path(build_ext.LIB_PATH)       # the tuning build reads GATSSPG_<KNOB> per launch
+from onepose_amd import GATsSuperGlue, synthetic
+from oracle import gatsspg_oracle as orc                          # (hyper-parameter defaults only)
+HP = dict(orc.DEFAULT_HPARAMS, match_threshold=0.0)
+sd = synthetic.make_state_dict(3)
+out = {}
+for prec in ('fp16x4', 'fp16x3'):
+    m = GATsSuperGlue(HP, precision=prec).eval()
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to('cuda:0')
+    for shape in ((1, 1000, 7000), (2, 300, 900)):       # 8-wave 128x128 mlp0 tile / the 4-wave tile
+        data = {k: torch.from_numpy(v).to('cuda:0') for k, v in synthetic.make_inputs(shape[0], shape[1], shape[2], 8, seed=11).items()}
+        for knobs in ('', 'SP_SCHED=3', 'SP_SCHED=2', 'SP_SCHED=0', 'SP_DIRECT_STORE=0', 'SP_SCHED=2,SP_DIRECT_STORE=0', 'SP_NST2=2'):   # (SP_NST2 bit 0 would change mlp0's TILE, whose statistics walk starts elsewhere: not bitwise)
+            for k in [k for k in os.environ if k.startswith('GATSSPG_')]:
+                del os.environ[k]
+            for kv in filter(None, knobs.split(',')):
+                a, b = kv.split('=')
+                os.environ['GATSSPG_' + a] = b
+            conf, m0, m1, s0, s1 = m.forward_batched(data)
+            torch.cuda.synchronize()
+            out[f'{prec} {shape} [{knobs}]'] = hashlib.sha256(conf.cpu().numpy().tobytes() + m0.cpu().numpy().tobytes()).hexdigest()
+print('SCHEDULE_PROBE ' + json.dumps(out))
+"""
+
+
+def test_split_loop_schedules_are_bit_identical():
+    """The schedules of the LDS-DMA split loop (gemm_split_glds.h: SCHED 0 / 2 / 3 / 4), the direct and the LDS-staged store of the
+    plain tiles and the two- / three-stage rings differ in WHEN an instruction is issued, never in the order of additions into an
+    accumulator: conf and matches must come out bit for bit the same.  Runs the tuning build (environment knobs read per launch) in a
+    process of its own; skipped when that library is not built (`python -m onepose_amd.build_ext --tuning`)."""
+    import json, subprocess, sys
+    from onepose_amd import build_ext
+    tuning = build_ext.tuning_path(build_ext.LIB_PATH)
+    if not os.path.exists(tuning):
+        pytest.skip("tuning build not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("GATSSPG_")}
+    r = subprocess.run([sys.executable, "-c", _SCHEDULE_PROBE, root], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("SCHEDULE_PROBE ")][-1]
+    out = json.loads(line[len("SCHEDULE_PROBE "):])
+    groups = {}
+    for key, digest in out.items():
+        groups.setdefault(key.split(" [")[0], {})[key] = digest
+    assert len(groups) == 4
+    for g, members in groups.items():
+        assert len(set(members.values())) == 1, f"{g}: schedules disagree bitwise: {members}"
