@@ -588,156 +588,179 @@ static PlaneSet planes(const unsigned short* wb, int prec, size_t hi, size_t lo,
 // schedule of the split loop in the fp16 modes (gemm_split_glds.h): 4 (default) = the slot schedule -- every MFMA of a step carries its share of the
 // step's VALU work, DMA requests and LDS reads, fenced slot by slot; 3 = the same with the next slab's reads in two bursts; 2 = DMA requests spread over
 // the step, split work left to hipcc's grouping; 0 = DMA requests in one burst behind the barrier; 1 = ping-pong wave groups.
-static int sp_direct_store() { return tuning_knob("SP_DIRECT_STORE", 3); }   // 3: +0.5 % per frame (profiles/r04_ab_live_direct_store.txt); bit 2 = mlp0 stores in front of its statistics (neutral)
-static int sp_sched() {
-    // interleaved single-process A/B runs (profiles/r04_ab_live_*.txt): 2 is 1.0-1.4 % faster per frame than 0, 3 another 1.0-1.6 %, 4 another 0.4 %
-    return tuning_knob("SP_SCHED", 4);   // (read per launch: tools/ab_live.py flips it inside one process)
-}
+// The PRODUCT library instantiates only what it runs: the fp16 modes on schedule 4 with direct stores (and the score kernel).  Every alternative --
+// other schedules, staged stores, ring depths, the bf16 modes and the exact fp32 arithmetic on this loop, the timing ablations -- is compiled into the
+// tuning build only (TUNING_BUILD), where the knobs below are read from the environment per launch (tools/ab_live.py flips them inside one process).
+#ifdef GATSSPG_TUNING
+constexpr bool TUNING_BUILD = true;
+#else
+constexpr bool TUNING_BUILD = false;
+#endif
+constexpr int SP_SCHED_DEFAULT = 4;          // profiles/r04_ab_live_*.txt: 2 is 1.0-1.4 % faster per frame than 0, 3 another 1.0-1.6 %, 4 another 0.4 %
+constexpr int SP_DIRECT_STORE_DEFAULT = 3;   // bit 0 the Q tiles of qkv_kv, bit 1 mlp3 leave straight from the accumulators (+0.5 % per frame); bit 2 = mlp0's
+                                             // tile stores in front of its statistics (neutral)
+static int sp_direct_store() { return tuning_knob("SP_DIRECT_STORE", SP_DIRECT_STORE_DEFAULT); }
+static int sp_sched() { return tuning_knob("SP_SCHED", SP_SCHED_DEFAULT); }
 
+template <class T, int SCHED, int EPI>
+static void launch_qkv_sp_v(const float* sc, const float* bqkv, const PlaneSet& p, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    allow_big_lds_sp<qkv_kv_sp_kernel<T, SCHED, EPI>>();
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, SCHED, EPI>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s, sc,
+                   bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
+}
 template <int MODE>
 static void launch_qkv_sp_t(const float* sc, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     using T = QkvSpTile<MODE>;
     const PlaneSet p = planes(wb, MODE, AttnWB::QKV_HI, AttnWB::QKV_LO, AttnWB::QKV_LO2, AttnWB::QKV_H16, AttnWB::QKV_L16);
     if constexpr (MODE >= 3) {
-        if (sp_sched() == 3) {   // the slot schedule (every MFMA carries its share of the step's VALU work), direct Q stores
-            allow_big_lds_sp<qkv_kv_sp_kernel<T, 3, 1>>();
-            GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 3, 1>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s,
-                           sc, bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
-            return;
-        }
-        if (sp_sched() == 4) {
-            allow_big_lds_sp<qkv_kv_sp_kernel<T, 4, 1>>();
-            GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 4, 1>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s,
-                           sc, bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
-            return;
-        }
-        if (sp_sched() == 2) {
-            if (sp_direct_store() & 1) {
-                allow_big_lds_sp<qkv_kv_sp_kernel<T, 2, 1>>();
-                GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 2, 1>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s,
-                               sc, bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
-                return;
+        if constexpr (TUNING_BUILD) {
+            const bool direct = sp_direct_store() & 1;
+            switch (sp_sched()) {
+                case 4: if (direct) break; return launch_qkv_sp_v<T, 4, 0>(sc, bqkv, p, w, s, hk);
+                case 3: return launch_qkv_sp_v<T, 3, 1>(sc, bqkv, p, w, s, hk);
+                case 2: return direct ? launch_qkv_sp_v<T, 2, 1>(sc, bqkv, p, w, s, hk) : launch_qkv_sp_v<T, 2, 0>(sc, bqkv, p, w, s, hk);
+                default: return launch_qkv_sp_v<T, 0, 0>(sc, bqkv, p, w, s, hk);
             }
-            allow_big_lds_sp<qkv_kv_sp_kernel<T, 2>>();
-            GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 2>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s,
-                           sc, bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
-            return;
         }
+        launch_qkv_sp_v<T, SP_SCHED_DEFAULT, 1>(sc, bqkv, p, w, s, hk);
+    } else {
+        launch_qkv_sp_v<T, 0, 0>(sc, bqkv, p, w, s, hk);   // bf16 modes (tuning builds: GATSSPG_SPLIT_LOOP_BF16X3 / _BF16X6)
     }
-    allow_big_lds_sp<qkv_kv_sp_kernel<T>>();
-    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s, sc,
-                   bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
 }
-// fp32 (MODE 0): Wqkv is the fp32 operator itself
+void launch_qkv_kv_sp(const float* sc, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    switch (w.prec) {
+#ifdef GATSSPG_TUNING
+        case 1: launch_qkv_sp_t<1>(sc, bqkv, wb, w, s, hk); break;
+        case 2: launch_qkv_sp_t<2>(sc, bqkv, wb, w, s, hk); break;
+#endif
+        case 3: launch_qkv_sp_t<3>(sc, bqkv, wb, w, s, hk); break;
+        default: launch_qkv_sp_t<4>(sc, bqkv, wb, w, s, hk); break;
+    }
+}
+// fp32 (MODE 0) on this loop: the operators are the fp32 matrices themselves.  Tuning builds only (GATSSPG_FP32_DMA; measured 8 % slower per frame
+// than the register-staged fp32 loop of gemm_f32_mfma.h): the product library never calls these.
 void launch_qkv_kv_dma(const float* Wqkv, const float* bqkv, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+#ifdef GATSSPG_TUNING
     using T = Fp32SpTile;
     allow_big_lds_sp<qkv_kv_sp_kernel<T, 2>>();
     GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 2>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s, Wqkv,
                    bqkv, reinterpret_cast<const unsigned short*>(Wqkv), nullptr, nullptr, w.Z, w.Q, w.kvpart, w.L);
+#else
+    (void)Wqkv; (void)bqkv; (void)w; (void)s; (void)hk;
+#endif
 }
 void launch_mlp0_dma(const float* W0, const float* b0, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+#ifdef GATSSPG_TUNING
     using T = Fp32SpTile;
     allow_big_lds_sp<mlp0_sp_kernel<T, 0, 2>>();
     GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_sp_kernel<T, 0, 2>), dim3(xcd_grid(512 / T::BM, active_tiles(w.L))), dim3(T::THREADS),
                    (size_t)T::RING_BYTES + 1024, s, W0, b0, reinterpret_cast<const unsigned short*>(W0), nullptr, nullptr, w.Z, w.Q,
                    reinterpret_cast<const unsigned short*>(w.Mop), w.ksumT, w.zsc, w.U, w.statpart, w.stats, stat_fused() ? w.statcnt : nullptr, w.L, g_trace);
+#else
+    (void)W0; (void)b0; (void)w; (void)s; (void)hk;
+#endif
 }
 void launch_mlp3_dma(const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+#ifdef GATSSPG_TUNING
     using T = Fp32SpTile;
     allow_big_lds_sp<mlp3_sp_kernel<T, 2>>();
     GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, 2>), dim3(xcd_grid(256 / T::BM, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s,
                    W3, b3, reinterpret_cast<const unsigned short*>(W3), nullptr, nullptr, w.U, w.stats, w.Z, w.L);
+#else
+    (void)W3; (void)b3; (void)w; (void)s; (void)hk;
+#endif
 }
 
-void launch_qkv_kv_sp(const float* sc, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
-    switch (w.prec) {
-        case 1: launch_qkv_sp_t<1>(sc, bqkv, wb, w, s, hk); break;
-        case 2: launch_qkv_sp_t<2>(sc, bqkv, wb, w, s, hk); break;
-        case 3: launch_qkv_sp_t<3>(sc, bqkv, wb, w, s, hk); break;
-        default: launch_qkv_sp_t<4>(sc, bqkv, wb, w, s, hk); break;
-    }
-}
-
-template <class T, int ABL = 0, int SCHED = 0>
+template <class T, int ABL = 0, int SCHED = 0, int EPI = 0>
 static void launch_mlp0_sp_t(const float* sc, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     const PlaneSet p = planes(wb, T::MODE, AttnWB::W0_HI, AttnWB::W0_LO, AttnWB::W0_LO2, AttnWB::W0_H16, AttnWB::W0_L16);
     const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
-    if constexpr (ABL == 0 && SCHED == 2) {
-        if ((sp_direct_store() & 4) && !stat_fused()) {   // tile stores in front of the statistics
-            allow_big_lds_sp<mlp0_sp_kernel<T, ABL, SCHED, 1>>();
-            GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_sp_kernel<T, ABL, SCHED, 1>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 1024, s, sc,
-                           b0, p.p0, p.p1, p.p2, w.Z, w.Q, w.Mpl, w.ksumT, w.zsc, w.U, w.statpart, w.stats, nullptr, w.L, g_trace);
-            return;
-        }
-    }
-    allow_big_lds_sp<mlp0_sp_kernel<T, ABL, SCHED>>();
-    GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_sp_kernel<T, ABL, SCHED>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 1024, s, sc, b0,
-                   p.p0, p.p1, p.p2, w.Z, w.Q, w.Mpl, w.ksumT, w.zsc, w.U, w.statpart, w.stats, stat_fused() ? w.statcnt : nullptr, w.L, g_trace);
+    allow_big_lds_sp<mlp0_sp_kernel<T, ABL, SCHED, EPI>>();
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_sp_kernel<T, ABL, SCHED, EPI>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 1024, s, sc, b0,
+                   p.p0, p.p1, p.p2, w.Z, w.Q, w.Mpl, w.ksumT, w.zsc, w.U, w.statpart, w.stats, (EPI == 0 && stat_fused()) ? w.statcnt : nullptr, w.L, g_trace);
 }
 template <int MODE>
 static void launch_mlp0_sp_m(const float* sc, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     // the 128-column tile (8 waves, one workgroup per CU) moves two thirds of the operand bytes per product through L2: taken when
     // its 4 x tiles workgroups make ONE round of the 256 CUs and fill at least three quarters of it (the headline shape: 252); with
     // fewer the 64-column tile (4 waves, two workgroups per CU, twice as many) fills the chip better, with more than one round its
-    // co-resident pairs overlap one workgroup's store tail with the other's loop (fp16x4, 8 frames per step: 179 vs 188 us per launch)
-    const int wide_min = tuning_knob("SP_MLP0_WIDE_MIN", 48), wide_max = tuning_knob("SP_MLP0_WIDE_MAX", 64);   // (per launch: tools/ab_live.py)
-#ifdef GATSSPG_TUNING
-    if constexpr (MODE == 4) {   // timing-only ablations of the main loop (wrong results)
-        const int abl = tuning_knob("SP_ABL", 0);
-        switch (abl) {
-            case 1: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 1>(sc, b0, wb, w, s, hk);     // no DMA after the prologue
-            case 2: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 2>(sc, b0, wb, w, s, hk);     // no MFMAs
-            case 4: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 4>(sc, b0, wb, w, s, hk);     // no split VALU
-            case 8: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 8>(sc, b0, wb, w, s, hk);     // no fragment reads
-            case 14: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 14>(sc, b0, wb, w, s, hk);   // DMA + barriers only
-            case 13: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 13>(sc, b0, wb, w, s, hk);   // MFMAs + barriers only
-            case 15: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 15>(sc, b0, wb, w, s, hk);   // barriers only (+ prologue, epilogue)
-            case 9: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 9>(sc, b0, wb, w, s, hk);     // no DMA, no reads: MFMAs + split
-            case 31: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 31>(sc, b0, wb, w, s, hk);   // skeleton without the tile's global stores
-            case 63: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 63>(sc, b0, wb, w, s, hk);   // skeleton without any epilogue
-            case 16: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 16>(sc, b0, wb, w, s, hk);   // full loop, no global stores of the tile
-            case 48: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 48>(sc, b0, wb, w, s, hk);   // full loop, no epilogue
-            case 100: return launch_mlp0_sp_t<Mlp0SpTileT<MODE>, 0>(sc, b0, wb, w, s, hk);   // (not an ablation) the one-wave-per-SIMD tile
-            case 101: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 1>(sc, b0, wb, w, s, hk);   // (not an ablation) the ping-pong schedule
-            case 102: return launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 1>(sc, b0, wb, w, s, hk);   // ping-pong on the 4-wave tile (groups on different SIMDs)
-            default: break;
-        }
-    }
-#endif
+    // co-resident pairs overlap one workgroup's store tail with the other's loop (fp16x4, 8 frames per step: 173 vs 185 us per launch)
+    const int wide_min = tuning_knob("SP_MLP0_WIDE_MIN", 48), wide_max = tuning_knob("SP_MLP0_WIDE_MAX", 64);
     const bool wide = active_tiles(w.L) / 2 >= wide_min && active_tiles(w.L) / 2 <= wide_max;
-    if constexpr (MODE == 4) {
-        if (tuning_knob("SP_NST2", -1) > 0 && (tuning_knob("SP_NST2", -1) & 1)) return launch_mlp0_sp_t<Mlp0SpTileN2<MODE>, 0, 2>(sc, b0, wb, w, s, hk);   // three workgroups per CU
+    if constexpr (TUNING_BUILD) {
+        if constexpr (MODE == 4) {   // timing-only ablations of the main loop (wrong results) and the alternative tiles
+            switch (tuning_knob("SP_ABL", 0)) {
+                case 1: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 1>(sc, b0, wb, w, s, hk);     // no DMA after the prologue
+                case 2: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 2>(sc, b0, wb, w, s, hk);     // no MFMAs
+                case 4: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 4>(sc, b0, wb, w, s, hk);     // no split VALU
+                case 8: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 8>(sc, b0, wb, w, s, hk);     // no fragment reads
+                case 14: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 14>(sc, b0, wb, w, s, hk);   // DMA + barriers only
+                case 13: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 13>(sc, b0, wb, w, s, hk);   // MFMAs + barriers only
+                case 15: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 15>(sc, b0, wb, w, s, hk);   // barriers only (+ prologue, epilogue)
+                case 9: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 9>(sc, b0, wb, w, s, hk);     // no DMA, no reads: MFMAs + split
+                case 31: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 31>(sc, b0, wb, w, s, hk);   // skeleton without the tile's global stores
+                case 63: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 63>(sc, b0, wb, w, s, hk);   // skeleton without any epilogue
+                case 16: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 16>(sc, b0, wb, w, s, hk);   // full loop, no global stores of the tile
+                case 48: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 48>(sc, b0, wb, w, s, hk);   // full loop, no epilogue
+                case 100: return launch_mlp0_sp_t<Mlp0SpTileT<MODE>, 0>(sc, b0, wb, w, s, hk);   // (not an ablation) the one-wave-per-SIMD tile
+                case 101: return launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 1>(sc, b0, wb, w, s, hk);   // (not an ablation) the ping-pong schedule
+                case 102: return launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 1>(sc, b0, wb, w, s, hk);   // ping-pong on the 4-wave tile (groups on different SIMDs)
+                default: break;
+            }
+            const int nst2 = tuning_knob("SP_NST2", -1);
+            if (nst2 > 0 && (nst2 & 1)) return launch_mlp0_sp_t<Mlp0SpTileN2<MODE>, 0, 2>(sc, b0, wb, w, s, hk);   // two-stage ring, three workgroups per CU
+        }
+        if constexpr (MODE >= 3) {
+            switch (sp_sched()) {
+                case 4: break;
+                case 3:
+                    if (wide && (tuning_knob("SP_NST4", 0) & 1)) return launch_mlp0_sp_t<Mlp0SpTileW4<MODE>, 0, 3>(sc, b0, wb, w, s, hk);   // four-stage ring
+                    return wide ? launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 3>(sc, b0, wb, w, s, hk) : launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 3>(sc, b0, wb, w, s, hk);
+                case 2:
+                    if ((sp_direct_store() & 4) && !stat_fused())   // tile stores in front of the statistics
+                        return wide ? launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 2, 1>(sc, b0, wb, w, s, hk) : launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 2, 1>(sc, b0, wb, w, s, hk);
+                    return wide ? launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 2>(sc, b0, wb, w, s, hk) : launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 2>(sc, b0, wb, w, s, hk);
+                default:
+                    return wide ? launch_mlp0_sp_t<Mlp0SpTileW<MODE>>(sc, b0, wb, w, s, hk) : launch_mlp0_sp_t<Mlp0SpTileN<MODE>>(sc, b0, wb, w, s, hk);
+            }
+        }
     }
     if constexpr (MODE >= 3) {
-        if (sp_sched() == 3) {
-            if (wide && (tuning_knob("SP_NST4", 0) & 1)) return launch_mlp0_sp_t<Mlp0SpTileW4<MODE>, 0, 3>(sc, b0, wb, w, s, hk);
-            if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 3>(sc, b0, wb, w, s, hk);
-            else launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 3>(sc, b0, wb, w, s, hk);
-            return;
-        }
-        if (sp_sched() == 4) {
-            if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 4>(sc, b0, wb, w, s, hk);
-            else launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 4>(sc, b0, wb, w, s, hk);
-            return;
-        }
-        if (sp_sched() == 2) {
-            if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 2>(sc, b0, wb, w, s, hk);
-            else launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 2>(sc, b0, wb, w, s, hk);
-            return;
-        }
+        if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, SP_SCHED_DEFAULT>(sc, b0, wb, w, s, hk);
+        else launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, SP_SCHED_DEFAULT>(sc, b0, wb, w, s, hk);
+    } else {   // bf16 modes (tuning builds)
+        if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>>(sc, b0, wb, w, s, hk);
+        else launch_mlp0_sp_t<Mlp0SpTileN<MODE>>(sc, b0, wb, w, s, hk);
     }
-    if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>>(sc, b0, wb, w, s, hk);
-    else launch_mlp0_sp_t<Mlp0SpTileN<MODE>>(sc, b0, wb, w, s, hk);
 }
 void launch_mlp0_sp(const float* sc, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     switch (w.prec) {
+#ifdef GATSSPG_TUNING
         case 1: launch_mlp0_sp_m<1>(sc, b0, wb, w, s, hk); break;
         case 2: launch_mlp0_sp_m<2>(sc, b0, wb, w, s, hk); break;
+#endif
         case 3: launch_mlp0_sp_m<3>(sc, b0, wb, w, s, hk); break;
         default: launch_mlp0_sp_m<4>(sc, b0, wb, w, s, hk); break;
     }
 }
 
+template <class T, int SCHED, int EPI>
+static void launch_mlp3_sp_v(const float* sc, const float* b3, const PlaneSet& p, int NT, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    allow_big_lds_sp<mlp3_sp_kernel<T, SCHED, EPI>>();
+    GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, SCHED, EPI>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc, b3,
+                   p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
+}
+// the schedule / store variants of one mlp3 tile (tuning builds); false = take the default
+template <class T>
+static bool launch_mlp3_sp_alt(const float* sc, const float* b3, const PlaneSet& p, int NT, const Workspace& w, hipStream_t s, ProfileHook* hk) {
+    const bool direct = sp_direct_store() & 2;
+    switch (sp_sched()) {
+        case 4: if (direct) return false; launch_mlp3_sp_v<T, 4, 0>(sc, b3, p, NT, w, s, hk); return true;
+        case 3: launch_mlp3_sp_v<T, 3, 1>(sc, b3, p, NT, w, s, hk); return true;
+        case 2: if (direct) launch_mlp3_sp_v<T, 2, 1>(sc, b3, p, NT, w, s, hk); else launch_mlp3_sp_v<T, 2, 0>(sc, b3, p, NT, w, s, hk); return true;
+        default: launch_mlp3_sp_v<T, 0, 0>(sc, b3, p, NT, w, s, hk); return true;
+    }
+}
 template <int MODE>
 static void launch_mlp3_sp_t(const float* sc, const float* b3, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     using T = Mlp3SpTile<MODE>;
@@ -746,67 +769,24 @@ static void launch_mlp3_sp_t(const float* sc, const float* b3, const unsigned sh
     if constexpr (MODE >= 3) {
         // more than one round of the three-stage ring's two workgroups per CU (batched frames, N_3D = 20000): the two-stage ring's three
         // per CU turn 1.46 rounds into one at 8 frames per step (fp16x4-b8: 0.565 vs 0.571 ms per frame, profiles/r04_ab_live_b8_tiles.txt)
+        using T2 = Mlp3SpTile2<MODE>;
         const int nst2 = tuning_knob("SP_NST2", -1);
-        if (nst2 >= 0 ? (nst2 & 2) != 0 : (256 / Mlp3SpTile2<MODE>::BM) * NT > 512) {
-            using T2 = Mlp3SpTile2<MODE>;
-            if (sp_sched() == 3) {
-                allow_big_lds_sp<mlp3_sp_kernel<T2, 3, 1>>();
-                GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T2, 3, 1>), dim3(xcd_grid(256 / T2::BM, NT)), dim3(T2::THREADS), (size_t)T2::RING_BYTES + 4096, s,
-                               sc, b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
-                return;
-            }
-            if (sp_sched() == 4) {
-                allow_big_lds_sp<mlp3_sp_kernel<T2, 4, 1>>();
-                GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T2, 4, 1>), dim3(xcd_grid(256 / T2::BM, NT)), dim3(T2::THREADS), (size_t)T2::RING_BYTES + 4096, s,
-                               sc, b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
-                return;
-            }
-            if (sp_direct_store() & 2) {
-                allow_big_lds_sp<mlp3_sp_kernel<T2, 2, 1>>();
-                GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T2, 2, 1>), dim3(xcd_grid(256 / T2::BM, NT)), dim3(T2::THREADS), (size_t)T2::RING_BYTES + 4096, s,
-                               sc, b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
-                return;
-            }
-            allow_big_lds_sp<mlp3_sp_kernel<T2, 2>>();
-            GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T2, 2>), dim3(xcd_grid(256 / T2::BM, NT)), dim3(T2::THREADS), (size_t)T2::RING_BYTES + 4096, s,
-                           sc, b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
-            return;
+        const bool two_stage = nst2 >= 0 ? (nst2 & 2) != 0 : (256 / T2::BM) * NT > 512;
+        if constexpr (TUNING_BUILD) {
+            if (two_stage ? launch_mlp3_sp_alt<T2>(sc, b3, p, NT, w, s, hk) : launch_mlp3_sp_alt<T>(sc, b3, p, NT, w, s, hk)) return;
         }
+        if (two_stage) launch_mlp3_sp_v<T2, SP_SCHED_DEFAULT, 1>(sc, b3, p, NT, w, s, hk);
+        else launch_mlp3_sp_v<T, SP_SCHED_DEFAULT, 1>(sc, b3, p, NT, w, s, hk);
+    } else {
+        launch_mlp3_sp_v<T, 0, 0>(sc, b3, p, NT, w, s, hk);   // bf16 modes (tuning builds)
     }
-    if constexpr (MODE >= 3) {
-        if (sp_sched() == 3) {
-            allow_big_lds_sp<mlp3_sp_kernel<T, 3, 1>>();
-            GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, 3, 1>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc,
-                           b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
-            return;
-        }
-        if (sp_sched() == 4) {
-            allow_big_lds_sp<mlp3_sp_kernel<T, 4, 1>>();
-            GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, 4, 1>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc,
-                           b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
-            return;
-        }
-        if (sp_sched() == 2) {
-            if (sp_direct_store() & 2) {
-                allow_big_lds_sp<mlp3_sp_kernel<T, 2, 1>>();
-                GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, 2, 1>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc,
-                               b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
-                return;
-            }
-            allow_big_lds_sp<mlp3_sp_kernel<T, 2>>();
-            GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, 2>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc,
-                           b3, p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
-            return;
-        }
-    }
-    allow_big_lds_sp<mlp3_sp_kernel<T>>();
-    GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc, b3,
-                   p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
 }
 void launch_mlp3_sp(const float* sc, const float* b3, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     switch (w.prec) {
+#ifdef GATSSPG_TUNING
         case 1: launch_mlp3_sp_t<1>(sc, b3, wb, w, s, hk); break;
         case 2: launch_mlp3_sp_t<2>(sc, b3, wb, w, s, hk); break;
+#endif
         case 3: launch_mlp3_sp_t<3>(sc, b3, wb, w, s, hk); break;
         default: launch_mlp3_sp_t<4>(sc, b3, wb, w, s, hk); break;
     }
