@@ -51,6 +51,19 @@ __device__ __forceinline__ void load_bias16(const float* b, int row0, int wm, in
         }
 }
 
+// the same 16 values per tile from an LDS table of the workgroup's BM bias values (filled by one LDS-DMA piece in front of the first slab
+// requests, read behind the loop: no global loads in the prologue, no bias registers across the loop)
+template <class T>
+__device__ __forceinline__ void read_bias16(const float* tab, int wm, int half, float (&bias)[T::TM][16]) {
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const vf4 b4 = *reinterpret_cast<const vf4*>(tab + (wm * T::TM + tm) * 32 + 8 * k + 4 * half);
+            bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
+        }
+}
+
 // =====================================================================================================
 // K1  QKV projection + KV / ksum partials (qkv_kv_kernel of gatsspg_gemm_kernels.hip on the split loop).
 //     128 x 64 tile on 4 waves (64 x 32 per wave), two stages (48 KiB): three workgroups per CU, so the 756 tiles of the headline
@@ -93,8 +106,11 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : 3)) void qkv_kv_sp_kernel
     const int c0 = ct * T::BN, ld = L.ld;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+    constexpr bool BIAS_TAB = (EPI & 2) != 0;   // bias through an LDS table behind the ring (T::BM floats)
+    static_assert(T::BM == 128, "one half piece of bias values");
+    float* btab = reinterpret_cast<float*>(smem_c + T::RING_BYTES);
     float bias[T::TM][16];
-    load_bias16<T>(bqkv, rt * 128, wm, half, bias);
+    if constexpr (!BIAS_TAB) load_bias16<T>(bqkv, rt * 128, wm, half, bias);
     const float inv = T::F16 ? 1.f / (sc[0] * T::ACT_SCALE) : 1.f;
     f32x16 acc[T::TM][T::TN];
     const size_t ro = (size_t)rt * 128 * BK;
@@ -106,15 +122,21 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : 3)) void qkv_kv_sp_kernel
     auto bsl = [&](int kt) { return Z + (size_t)kt * BK * ld + c0; };
     SpPlainHooks<true> hooks;
     SpNoBx nobx;
-    gemm_mainloop_sp<T, D / BK, decltype(apl), decltype(bsl), SpPlainHooks<true>, SpNoBx, 0, SCHED>(
-        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx, nullptr, SpNoPre(), false, T::F32 ? D * 4 : 64);
+    auto pre = [&]() {
+        if constexpr (BIAS_TAB) {
+            if (wave == 0 && lane < 32) glds16(bqkv + rt * 128 + 4 * lane, btab);   // 128 floats: half a piece
+        }
+    };
+    gemm_mainloop_sp<T, D / BK, decltype(apl), decltype(bsl), SpPlainHooks<true>, SpNoBx, 0, SCHED, decltype(pre)>(
+        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx, nullptr, pre, false, T::F32 ? D * 4 : 64);
+    if constexpr (BIAS_TAB) read_bias16<T>(btab, wm, half, bias);
 
     if (rt < 2) {
 #pragma unroll
         for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][0][r] = elu1_select(fmaf(acc[tm][0][r], inv, bias[tm][r])) + 1.f;
-        if constexpr (EPI == 1) store_tile_direct<T>(acc, Qbuf + (size_t)rt * 128 * ld + c0, ld, [](int, float v) { return v; });
+        if constexpr (EPI & 1) store_tile_direct<T>(acc, Qbuf + (size_t)rt * 128 * ld + c0, ld, [](int, float v) { return v; });
         else store_tile_via_lds<T>(acc, smem, Qbuf + (size_t)rt * 128 * ld + c0, ld, [](int, float v) { return v; });
         return;
     }
@@ -267,8 +289,11 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::TM == 4 ? 1 : (T::WAVE
     // (filled by ONE LDS-DMA piece in front of the first slab requests: no register hop, no wait of its own)
     // requested before the main loop (behind it the two dependent round trips would sit on the critical path: measured 3.9 k cycles of
     // a 39 k-cycle kernel); hipcc parks some of the 32 values in scratch across the loop, which costs two scratch instructions each
+    constexpr bool BIAS_TAB = (EPI & 2) != 0;   // bias through a second LDS table (T::BM floats behind the ksum table)
+    static_assert(T::BM == 128, "one half piece of bias values");
+    float* btab = tab + 256;
     float bias[T::TM][16];
-    load_bias16<T>(b0, rt * T::BM, wm, half, bias);
+    if constexpr (!BIAS_TAB) load_bias16<T>(b0, rt * T::BM, wm, half, bias);
     const float inv = T::F16 ? 1.f / (sc[1] * T::ACT_SCALE) : 1.f;
     f32x16 acc[T::TM][T::TN];
     const size_t ro = (size_t)rt * T::BM * BK;   // slab-major planes: (m, k) at ((k / 32) * 512 + m) * 32 + k % 32
@@ -291,11 +316,15 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::TM == 4 ? 1 : (T::WAVE
     SpNoBx nobx;
     auto pre = [&]() {
         if (wave == 0) glds16(ksumT + (size_t)ts.seg * H * DH + 4 * lane, tab);   // [4][64] floats = 1 KiB
+        if constexpr (BIAS_TAB) {
+            if (wave == 1 && lane < 32) glds16(b0 + rt * T::BM + 4 * lane, btab);   // 128 floats: half a piece
+        }
     };
     gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), AttnFoldSp<T::TM>, SpNoBx, ABL, SCHED, decltype(pre)>(
         reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx, &tr, pre, SP_TRACE_ON(trace), T::F32 ? 512 * 4 : 64);
     if (SP_TRACE_ON(trace)) tr.t[9] = __builtin_readcyclecounter();    // behind the loop's last barrier
     hooks.template fold<3>(reinterpret_cast<f32x16(&)[T::TM]>(acc));
+    if constexpr (BIAS_TAB) read_bias16<T>(btab, wm, half, bias);
     if constexpr (ABL & 32) {   // timing only: no epilogue at all (one store keeps the accumulators alive)
         if (acc[0][0][0] == 123.456f) U[0] = acc[T::TM - 1][0][5];
         return;
@@ -365,7 +394,7 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::TM == 4 ? 1 : (T::WAVE
             }
         }
     };
-    if constexpr (EPI == 1) {   // (stat_final launch only) the tile's stores drain while the statistics are summed
+    if constexpr (EPI & 1) {   // (stat_final launch only) the tile's stores drain while the statistics are summed
         tile_stores();
         asm volatile("" ::: "memory");
         tile_statistics();
@@ -443,13 +472,17 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::NST == 2 ? 3 : 2)) voi
     static_assert(T::WAVES >= 4, "statistics table fill: one piece per wave");
     // start from (residual + bias) x the accumulator scale (exact: a power of two)
     f32x16 acc[T::TM][T::TN];
+    {
+        float bias[T::TM][16];   // (four 16-byte loads per 32-row tile instead of sixteen broadcast dword loads)
+        load_bias16<T>(b3, rt * T::BM, wm, half, bias);
 #pragma unroll
-    for (int tm = 0; tm < T::TM; ++tm)
+        for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rt * T::BM + (wm * T::TM + tm) * 32 + mfma_row(r, half);
-            acc[tm][0][r] = (Z[(size_t)row * ld + c0 + wn * 32 + l31] + b3[row]) * scale;
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * T::BM + (wm * T::TM + tm) * 32 + mfma_row(r, half);
+                acc[tm][0][r] = (Z[(size_t)row * ld + c0 + wn * 32 + l31] + bias[tm][r]) * scale;
+            }
+    }
     const size_t ro = (size_t)rt * T::BM * BK;
     auto apl = [&](int kt, int pl) -> const void* {
         if constexpr (T::F32) return reinterpret_cast<const float*>(P0) + (size_t)rt * T::BM * 512 + kt * BK;   // fp32 W3 [256][512]
@@ -464,7 +497,7 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::NST == 2 ? 3 : 2)) voi
     };
     gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), SpPlainHooks<false>, InstNormBx, 0, SCHED, decltype(pre)>(
         reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, bx, nullptr, pre, false, T::F32 ? 512 * 4 : 64);
-    if constexpr (EPI == 1) store_tile_direct<T>(acc, Z + (size_t)rt * T::BM * ld + c0, ld, [inv](int, float v) { return v * inv; });
+    if constexpr (EPI & 1) store_tile_direct<T>(acc, Z + (size_t)rt * T::BM * ld + c0, ld, [inv](int, float v) { return v * inv; });
     else store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [inv](int, float v) { return v * inv; });
 }
 
@@ -601,12 +634,15 @@ constexpr int SP_DIRECT_STORE_DEFAULT = 3;   // bit 0 the Q tiles of qkv_kv, bit
                                              // tile stores in front of its statistics (neutral)
 static int sp_direct_store() { return tuning_knob("SP_DIRECT_STORE", SP_DIRECT_STORE_DEFAULT); }
 static int sp_sched() { return tuning_knob("SP_SCHED", SP_SCHED_DEFAULT); }
+// 1: qkv_kv / mlp0 read their bias from an LDS table filled by one LDS-DMA piece (no global loads in front of the first slab requests); 0: per-lane
+// 16-byte global loads before the loop (schedule 4 only; the other schedules keep the loads)
+static int sp_bias_table() { return tuning_knob("SP_BIAS_TABLE", 1); }
 
 template <class T, int SCHED, int EPI>
 static void launch_qkv_sp_v(const float* sc, const float* bqkv, const PlaneSet& p, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     allow_big_lds_sp<qkv_kv_sp_kernel<T, SCHED, EPI>>();
-    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, SCHED, EPI>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s, sc,
-                   bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, SCHED, EPI>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES + 1024, s,
+                   sc, bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
 }
 template <int MODE>
 static void launch_qkv_sp_t(const float* sc, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
@@ -616,13 +652,16 @@ static void launch_qkv_sp_t(const float* sc, const float* bqkv, const unsigned s
         if constexpr (TUNING_BUILD) {
             const bool direct = sp_direct_store() & 1;
             switch (sp_sched()) {
-                case 4: if (direct) break; return launch_qkv_sp_v<T, 4, 0>(sc, bqkv, p, w, s, hk);
+                case 4:
+                    if (!direct) return launch_qkv_sp_v<T, 4, 0>(sc, bqkv, p, w, s, hk);
+                    if (!sp_bias_table()) return launch_qkv_sp_v<T, 4, 1>(sc, bqkv, p, w, s, hk);
+                    break;
                 case 3: return launch_qkv_sp_v<T, 3, 1>(sc, bqkv, p, w, s, hk);
                 case 2: return direct ? launch_qkv_sp_v<T, 2, 1>(sc, bqkv, p, w, s, hk) : launch_qkv_sp_v<T, 2, 0>(sc, bqkv, p, w, s, hk);
                 default: return launch_qkv_sp_v<T, 0, 0>(sc, bqkv, p, w, s, hk);
             }
         }
-        launch_qkv_sp_v<T, SP_SCHED_DEFAULT, 1>(sc, bqkv, p, w, s, hk);
+        launch_qkv_sp_v<T, SP_SCHED_DEFAULT, 3>(sc, bqkv, p, w, s, hk);   // direct Q stores, bias through its LDS table
     } else {
         launch_qkv_sp_v<T, 0, 0>(sc, bqkv, p, w, s, hk);   // bf16 modes (tuning builds: GATSSPG_SPLIT_LOOP_BF16X3 / _BF16X6)
     }
@@ -643,7 +682,7 @@ void launch_qkv_kv_dma(const float* Wqkv, const float* bqkv, const Workspace& w,
 #ifdef GATSSPG_TUNING
     using T = Fp32SpTile;
     allow_big_lds_sp<qkv_kv_sp_kernel<T, 2>>();
-    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 2>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES, s, Wqkv,
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, 2>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES + 1024, s, Wqkv,
                    bqkv, reinterpret_cast<const unsigned short*>(Wqkv), nullptr, nullptr, w.Z, w.Q, w.kvpart, w.L);
 #else
     (void)Wqkv; (void)bqkv; (void)w; (void)s; (void)hk;
@@ -654,7 +693,7 @@ void launch_mlp0_dma(const float* W0, const float* b0, const Workspace& w, hipSt
     using T = Fp32SpTile;
     allow_big_lds_sp<mlp0_sp_kernel<T, 0, 2>>();
     GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_sp_kernel<T, 0, 2>), dim3(xcd_grid(512 / T::BM, active_tiles(w.L))), dim3(T::THREADS),
-                   (size_t)T::RING_BYTES + 1024, s, W0, b0, reinterpret_cast<const unsigned short*>(W0), nullptr, nullptr, w.Z, w.Q,
+                   (size_t)T::RING_BYTES + 2048, s, W0, b0, reinterpret_cast<const unsigned short*>(W0), nullptr, nullptr, w.Z, w.Q,
                    reinterpret_cast<const unsigned short*>(w.Mop), w.ksumT, w.zsc, w.U, w.statpart, w.stats, stat_fused() ? w.statcnt : nullptr, w.L, g_trace);
 #else
     (void)W0; (void)b0; (void)w; (void)s; (void)hk;
@@ -676,8 +715,8 @@ static void launch_mlp0_sp_t(const float* sc, const float* b0, const unsigned sh
     const PlaneSet p = planes(wb, T::MODE, AttnWB::W0_HI, AttnWB::W0_LO, AttnWB::W0_LO2, AttnWB::W0_H16, AttnWB::W0_L16);
     const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
     allow_big_lds_sp<mlp0_sp_kernel<T, ABL, SCHED, EPI>>();
-    GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_sp_kernel<T, ABL, SCHED, EPI>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 1024, s, sc, b0,
-                   p.p0, p.p1, p.p2, w.Z, w.Q, w.Mpl, w.ksumT, w.zsc, w.U, w.statpart, w.stats, (EPI == 0 && stat_fused()) ? w.statcnt : nullptr, w.L, g_trace);
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_sp_kernel<T, ABL, SCHED, EPI>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 2048, s, sc, b0,
+                   p.p0, p.p1, p.p2, w.Z, w.Q, w.Mpl, w.ksumT, w.zsc, w.U, w.statpart, w.stats, (!(EPI & 1) && stat_fused()) ? w.statcnt : nullptr, w.L, g_trace);
 }
 template <int MODE>
 static void launch_mlp0_sp_m(const float* sc, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
@@ -712,7 +751,9 @@ static void launch_mlp0_sp_m(const float* sc, const float* b0, const unsigned sh
         }
         if constexpr (MODE >= 3) {
             switch (sp_sched()) {
-                case 4: break;
+                case 4:
+                    if (sp_bias_table()) break;
+                    return wide ? launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 4>(sc, b0, wb, w, s, hk) : launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 4>(sc, b0, wb, w, s, hk);
                 case 3:
                     if (wide && (tuning_knob("SP_NST4", 0) & 1)) return launch_mlp0_sp_t<Mlp0SpTileW4<MODE>, 0, 3>(sc, b0, wb, w, s, hk);   // four-stage ring
                     return wide ? launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, 3>(sc, b0, wb, w, s, hk) : launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, 3>(sc, b0, wb, w, s, hk);
@@ -726,8 +767,8 @@ static void launch_mlp0_sp_m(const float* sc, const float* b0, const unsigned sh
         }
     }
     if constexpr (MODE >= 3) {
-        if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, SP_SCHED_DEFAULT>(sc, b0, wb, w, s, hk);
-        else launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, SP_SCHED_DEFAULT>(sc, b0, wb, w, s, hk);
+        if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, SP_SCHED_DEFAULT, 2>(sc, b0, wb, w, s, hk);   // (EPI 2: bias through its LDS table)
+        else launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, SP_SCHED_DEFAULT, 2>(sc, b0, wb, w, s, hk);
     } else {   // bf16 modes (tuning builds)
         if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>>(sc, b0, wb, w, s, hk);
         else launch_mlp0_sp_t<Mlp0SpTileN<MODE>>(sc, b0, wb, w, s, hk);
