@@ -37,7 +37,7 @@ using QkvTileB = GemmTile<128, QKV_BN, 2, 2, false>;      // split-bf16 alternat
 // PREC = 0: exact fp32 MFMA.  PREC = 1: split-bf16 main loop on the pre-split weight planes Whi / Wlo.
 // (forcing 80 VGPRs so that three 8-wave workgroups fit a CU -- the 756 tiles of the headline shape then fit 768 slots in one
 // round -- was measured: kernel -2 %, frames/s in flight unchanged; not kept)
-template <class T, int PREC = 0>
+template <class T, int PREC = 0, int BT = 0>
 __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel(const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
                                                             const unsigned short* __restrict__ Whi,
                                                             const unsigned short* __restrict__ Wlo,
@@ -67,7 +67,14 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel
                 bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
             }
     };
-    if constexpr (PREC != 2) load_bias();
+    // BT: the bias through an LDS table behind the operand buffers instead (read_bias16, gemm_f32_mfma.h)
+    float* btab = smem + smem_floats_mainloop<T, PREC>();
+    if constexpr (BT) {
+        static_assert(T::BM == 128 && T::KS == 1, "half a piece of bias values, one wave group");
+        if ((tid >> 6) == 0 && lane < 32) glds16(bqkv + rt * 128 + 4 * lane, btab);
+    } else if constexpr (PREC != 2) {
+        load_bias();
+    }
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     if constexpr (PREC == 1 || PREC >= 3) {   // PREC >= 3: the planes hold fp16 terms, the products run on the f16 MFMA (4: four products)
@@ -89,7 +96,8 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel
             acc, smem, D / BK, [&](int kt) { return A + kt * BK; }, D,
             [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
     }
-    if constexpr (PREC == 2) load_bias();
+    if constexpr (BT) read_bias16<T>(btab, wm, half, bias);
+    else if constexpr (PREC == 2) load_bias();
 
     if (rt < 2) {
 #pragma unroll
@@ -341,7 +349,7 @@ static constexpr unsigned long long* g_trace = nullptr;
 #endif
 
 // ABL (profiling builds only, wrong results): main-loop ablations of gemm_mainloop_ex.  PREC as in qkv_kv_kernel.
-template <class T, int ABL = 0, int PREC = 0>
+template <class T, int ABL = 0, int PREC = 0, int BT = 0>
 __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                    const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
                                                    const unsigned short* __restrict__ Wl2,
@@ -375,7 +383,13 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(c
                 bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
             }
     };
-    if constexpr (PREC < 2) load_bias();
+    float* btab = smem + smem_floats_mainloop<T, PREC>() + AttnFoldHooks::ZP_FLOATS;   // BT: bias through an LDS table (see qkv_kv_kernel)
+    if constexpr (BT) {
+        static_assert(T::BM == 128 && T::KS == 1, "half a piece of bias values, one wave group");
+        if ((tid >> 6) == 0 && lane < 32) glds16(b0 + rt * T::BM + 4 * lane, btab);
+    } else if constexpr (PREC < 2) {
+        load_bias();
+    }
     f32x16 acc[T::TM][T::TN];
     zero_acc(acc);
     // ABL == 5 (profiling): every workgroup streams the SAME weight panel and the SAME column tile (cache-hot operands)
@@ -412,7 +426,8 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(c
     }
     acc[0][0] = hooks.kept;
     ksplit_reduce<T>(acc, smem);
-    if constexpr (PREC >= 2) load_bias();
+    if constexpr (BT) read_bias16<T>(btab, wm, half, bias);
+    else if constexpr (PREC >= 2) load_bias();
     const unsigned long long t_loop = trace ? wall_clock64() : 0;
     constexpr int TS = T::BN + 1;
     float* Tl = smem;  // [BM][BN + 1]
@@ -920,12 +935,12 @@ void allow_big_lds() {
     }
 }
 
-template <class T, int PREC>
+template <class T, int PREC, int BT = 0>
 static void launch_qkv_t(const float* Wqkv, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s,
                          ProfileHook* hk) {
     const int NT = active_tiles(w.L);
-    allow_big_lds<qkv_kv_kernel<T, PREC>>();
-    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_kernel<T, PREC>), dim3(xcd_grid(6, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>()), s,
+    allow_big_lds<qkv_kv_kernel<T, PREC, BT>>();
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_kernel<T, PREC, BT>), dim3(xcd_grid(6, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>() + 512 * BT), s,
                    Wqkv, bqkv, wb ? wb + (PREC >= 3 ? AttnWB::QKV_H16 : AttnWB::QKV_HI) : nullptr,
                    wb ? wb + (PREC >= 3 ? AttnWB::QKV_L16 : AttnWB::QKV_LO) : nullptr, wb ? wb + AttnWB::QKV_LO2 : nullptr, w.Z,
                    w.Q, w.kvpart, w.L);
@@ -950,6 +965,10 @@ bool split_loop_glds(int prec) {
 
 // fp32 arithmetic on the LDS-DMA loop (tuning builds: GATSSPG_FP32_DMA, bit 0 qkv_kv, 1 mlp0, 2 mlp3); shapes whose launches leave CUs
 // empty keep the K-split tiles of the register-staged loop
+// fp32 qkv_kv / mlp0 (8-wave tiles): bias through an LDS table filled by half an LDS-DMA piece at kernel entry (read_bias16) instead of per-lane loads
+// (tuning builds; measured -0.2 % in flight / -0.7 % one at a time at the headline shape: the split loop's gain from its table came with 38 fewer
+//  registers per wave, which this loop does not get)
+[[maybe_unused]] static int fp32_bias_table() { return tuning_knob("FP32_BIAS_TABLE", 0); }
 static int fp32_dma(const Workspace& w) {
     const int m = tuning_knob("FP32_DMA", 0);
     return (w.prec == 0 && active_tiles(w.L) > 64) ? m : 0;
@@ -967,6 +986,9 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* w
     if (w.prec == 1 && tq == 1) launch_qkv_t<QkvTileB, 1>(Wqkv, bqkv, wb, w, s, hk);
     else if (w.prec == 1) launch_qkv_t<QkvTileW8, 1>(Wqkv, bqkv, wb, w, s, hk);
     else if (w.prec == 2) launch_qkv_t<QkvTileW8, 2>(Wqkv, bqkv, wb, w, s, hk);
+#ifdef GATSSPG_TUNING
+    else if (fp32_bias_table()) launch_qkv_t<QkvTileW8, 0, 1>(Wqkv, bqkv, wb, w, s, hk);
+#endif
     else launch_qkv_t<QkvTileW8, 0>(Wqkv, bqkv, wb, w, s, hk);
 }
 
@@ -983,13 +1005,13 @@ void launch_kv_final(const float* W0, const Workspace& w, int cross, const float
                    W0, w.Mop, w.Mpl, w.ksumT, w.zsc, w.statcnt, W0 - AttnW::W0 + AttnW::SC, w.L, cross, w.prec, abl);
 }
 
-template <class T, int ABL, int PREC>
+template <class T, int ABL, int PREC, int BT = 0>
 static void launch_mlp0_t(const float* W0, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s,
                           ProfileHook* hk) {
-    allow_big_lds<mlp0_kernel<T, ABL, PREC>>();
+    allow_big_lds<mlp0_kernel<T, ABL, PREC, BT>>();
     const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
-    GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_kernel<T, ABL, PREC>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
-                   (smem_bytes<T, PREC>() + sizeof(float) * AttnFoldHooks::ZP_FLOATS), s, W0, b0,
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_kernel<T, ABL, PREC, BT>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
+                   (smem_bytes<T, PREC>() + sizeof(float) * AttnFoldHooks::ZP_FLOATS + 512 * BT), s, W0, b0,
                    wb ? wb + (PREC >= 3 ? AttnWB::W0_H16 : AttnWB::W0_HI) : nullptr, wb ? wb + (PREC >= 3 ? AttnWB::W0_L16 : AttnWB::W0_LO) : nullptr,
                    wb ? wb + AttnWB::W0_LO2 : nullptr, w.Z, w.Q, w.Mop, w.Mpl, w.ksumT, w.U,
                    w.statpart, w.stats, stat_fused() ? w.statcnt : nullptr, w.L, g_trace);
@@ -1029,6 +1051,9 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else if (t0 == 12) launch_mlp0_t<Mlp0TileW8, 2, 0>(W0, b0, wb, w, s, hk);   // no loads, no LDS writes
     else if (t0 == 15) launch_mlp0_t<Mlp0TileW8, 5, 0>(W0, b0, wb, w, s, hk);   // all workgroups stream the same (cache-hot) panels
     else if (t0 == 16) launch_mlp0_t<Mlp0TileW8, 6, 0>(W0, b0, wb, w, s, hk);   // every load L1-hot
+#endif
+#ifdef GATSSPG_TUNING
+    else if (fp32_bias_table()) launch_mlp0_t<Mlp0TileW8, 0, 0, 1>(W0, b0, wb, w, s, hk);
 #endif
     else launch_mlp0_t<Mlp0TileW8, 0, 0>(W0, b0, wb, w, s, hk);
     // (the InstanceNorm statistics are finished inside the mlp.0 launch by its last workgroups: stat_last_block; tuning builds keep the

@@ -51,19 +51,6 @@ __device__ __forceinline__ void load_bias16(const float* b, int row0, int wm, in
         }
 }
 
-// the same 16 values per tile from an LDS table of the workgroup's BM bias values (filled by one LDS-DMA piece in front of the first slab
-// requests, read behind the loop: no global loads in the prologue, no bias registers across the loop)
-template <class T>
-__device__ __forceinline__ void read_bias16(const float* tab, int wm, int half, float (&bias)[T::TM][16]) {
-#pragma unroll
-    for (int tm = 0; tm < T::TM; ++tm)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const vf4 b4 = *reinterpret_cast<const vf4*>(tab + (wm * T::TM + tm) * 32 + 8 * k + 4 * half);
-            bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
-        }
-}
-
 // =====================================================================================================
 // K1  QKV projection + KV / ksum partials (qkv_kv_kernel of gatsspg_gemm_kernels.hip on the split loop).
 //     128 x 64 tile on 4 waves (64 x 32 per wave), two stages (48 KiB): three workgroups per CU, so the 756 tiles of the headline

@@ -854,6 +854,26 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float
 
 // Epilogue helper: the accumulator tile leaves through LDS as 16-byte stores (16 lanes cover one 256-byte row segment
 // of a 64-column tile) instead of 4-byte stores straight from the MFMA layout (measured on mlp0: -3 %).
+// One LDS-DMA request: lane i moves 16 bytes from its global address to lds + 16 i (global_load_lds_dwordx4; M0 = the wave-uniform LDS base).
+__device__ __forceinline__ void glds16(const void* g, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0,
+                                     0);
+}
+// A lane's 16 bias values per 32-row MFMA tile (rows 8 k + 4 half + 0..3) from an LDS table of the workgroup's BM bias values.  The table is
+// filled by HALF an LDS-DMA piece (32 lanes x 16 bytes) requested at kernel entry -- older than every operand load of the main loop, so the
+// loop's own waits and barriers cover and publish it -- and read behind the loop: no bias registers across the loop, no per-lane global loads
+// in front of the first operand requests (frames in flight: +3..4 % on the split loop, profiles/r04_ab_live_bias_table.txt).
+template <class T>
+__device__ __forceinline__ void read_bias16(const float* tab, int wm, int half, float (&bias)[T::TM][16]) {
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const vf4 b4 = *reinterpret_cast<const vf4*>(tab + (wm * T::TM + tm) * 32 + 8 * k + 4 * half);
+            bias[tm][4 * k + 0] = b4[0]; bias[tm][4 * k + 1] = b4[1]; bias[tm][4 * k + 2] = b4[2]; bias[tm][4 * k + 3] = b4[3];
+        }
+}
+
 // f(row, v) is applied on the way in; dst points at the tile origin, ld is its row stride; both 16-byte aligned.
 // smem must be free (the main loop ends on a barrier) and hold BM * (BN + 4) floats.
 template <class T, class F>

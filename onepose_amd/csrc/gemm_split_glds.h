@@ -38,10 +38,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__device__ __forceinline__ void glds16(const void* g, void* lds) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0,
-                                     0);
-}
+// (glds16: gemm_f32_mfma.h)
 // counted wait for this wave's LDS-DMA pieces + its own LDS reads, then the workgroup barrier (no vmcnt(0) drain)
 template <int VM>
 __device__ __forceinline__ void wait_dma_barrier() {
