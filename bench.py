@@ -34,8 +34,14 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# The HIP runtime deals a process's streams onto a pool of GPU_MAX_HW_QUEUES hardware queues (4 unless set) and two streams on one
+# queue run strictly one behind the other: --streams frames are only "in flight" if every stream has a queue of its own.  Read
+# when the runtime loads, i.e. before `import torch`; a value the caller exported wins.  (tools/sweep_queues.sh,
+# profiles/r04_sweep_hw_queues.txt: 4 streams on >= 5 queues +2.4 % frames/s at the headline shape, +7..11 % at 500/2000.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -691,7 +697,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--reps", type=int, default=5, help="the K-step timed pass is repeated this many times; the median is reported")
-    ap.add_argument("--streams", type=int, default=3, help="query frames kept in flight per GPU (one HIP stream each)")
+    ap.add_argument("--streams", type=int, default=4, help="query frames kept in flight per GPU (one HIP stream each; needs "
+                                                             "GPU_MAX_HW_QUEUES > streams, set to 8 at the top of this file)")
     ap.add_argument("--config", default="headline", choices=list(CONFIGS),
                     help="workload: 'headline' = BASELINE configs[1] (the value the driver records); the others are "
                          "separately reported lines (config.workload names them)")
@@ -898,7 +905,8 @@ def main():
                        + ("the score contraction of the dual softmax on the same split arithmetic (fp32-class modes only); final_proj, GATs, "
                           "the KV pass and every reduction fp32" if cfg["precision"] in ("bf16x6", "fp16x4") else "final_proj, score, GATs fp32"),
                        "n_2d": n1, "n_3d": n2, "num_leaf": NUM_LEAF, "batch": bsz, "steps_per_gpu": K, "frames_per_gpu": K * bsz,
-                       "frames_in_flight_per_gpu": S * bsz, "timed_pass_repetitions": R,
+                       "frames_in_flight_per_gpu": S * bsz, "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "timed_pass_repetitions": R,
                        "timed_pass_seconds": [round(t, 5) for t in reps], "reported": "median repetition",
                        "value_is": f"all frames of a pass / the median of the {R} timed passes; one pass = exactly {K} steps between barrier + "
                                    f"synchronize pairs ({elapsed * 1e3:.1f} ms here: with the driver's --steps 20 the number rests on {R} passes of ~16 ms)",
