@@ -1,0 +1,52 @@
+"""Host side of "frames in flight" (DESIGN 14k).  Query frames are independent (inference.py:97-182 walks them one by one), so a
+serving process overlaps them: every frame in flight on a HIP stream of its own.  Two facts of the HIP runtime decide how many pay:
+
+* streams are dealt onto a pool of GPU_MAX_HW_QUEUES hardware queues -- 4 unless the variable is set -- and two streams on one queue run
+  strictly one behind the other (with the default pool a fourth stream adds nothing);
+* the variable is read when the runtime initialises, i.e. at the first HIP call of the process, not when torch is imported
+  (profiles/r04_ab_live_four_in_flight.txt).
+
+Measured optimum (profiles/r04_sweep_hw_queues.txt): FOUR frames in flight on >= 5 queues; a fifth concurrently running frame loses 5-20 %.
+"""
+import os
+import warnings
+
+import torch
+
+HW_QUEUES = 8
+FRAMES_IN_FLIGHT = 4
+
+
+def configure_hip_queues(n=HW_QUEUES):
+    """Export GPU_MAX_HW_QUEUES=n unless the caller already did; returns the value in force (str) or None when it is too late
+    (the runtime of this process is initialised and the variable was not set: the pool stays at the runtime's default)."""
+    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if cur is not None:
+        return cur
+    if torch.cuda.is_initialized():   # (no torch.cuda.is_available() in front of the export: it is itself a HIP call)
+        warnings.warn("onepose_amd: the HIP runtime is already initialised with its default pool of 4 hardware queues; export "
+                      f"GPU_MAX_HW_QUEUES={n} before the first HIP call to keep {FRAMES_IN_FLIGHT} frames in flight (DESIGN 14k)", stacklevel=2)
+        return None
+    os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+    return str(n)
+
+
+class StreamRing:
+    """n HIP streams dealt round-robin: ``with ring.next(): pred, conf = model(data)`` keeps n frames in flight (the modules cache
+    their workspaces per stream; every frame in flight needs outputs of its own, which the modules allocate per call)."""
+
+    def __init__(self, device, n=FRAMES_IN_FLIGHT):
+        if not torch.cuda.is_available():
+            raise RuntimeError("StreamRing needs a ROCm GPU (there is no CPU path)")
+        self.device = torch.device(device)
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(n)]
+        self._i = 0
+
+    def next(self):
+        s = self.streams[self._i % len(self.streams)]
+        self._i += 1
+        return torch.cuda.stream(s)
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()

@@ -11,6 +11,8 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+import onepose_amd  # noqa: E402,F401  (before any test module makes a HIP call: the package exports GPU_MAX_HW_QUEUES, runtime.py)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -778,6 +778,30 @@ def test_one_module_on_two_streams_does_not_share_scratch():
             assert torch.equal(x, y)
 
 
+def test_stream_ring_keeps_four_frames_in_flight_with_serial_results():
+    """onepose_amd.StreamRing (runtime.py): eight frames dealt over four streams through the nn.Module contract,
+    three rounds back to back, give the bits of running them one after the other; the queue pool is the one the package asked for."""
+    import os
+    from onepose_amd import StreamRing, runtime
+    assert int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) > runtime.FRAMES_IN_FLIGHT   # conftest imports the package before the first HIP call
+    sd = synthetic.make_state_dict(0)
+    model = make_model(sd, dict(HP, match_threshold=0.0))
+    frames = [to_dev(synthetic.make_inputs(1, 260 + 8 * i, 700 + 16 * i, 8, seed=90 + i)) for i in range(8)]
+    serial = [model.forward_batched(f) for f in frames]
+    torch.cuda.synchronize()
+    ring = StreamRing(dev())
+    assert len(ring.streams) == 4
+    for _ in range(3):
+        outs = []
+        for f in frames:
+            with ring.next():
+                outs.append(model.forward_batched(f))
+    ring.synchronize()
+    for a, b in zip(serial, outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 def test_unknown_flag_bits_are_refused():
     lib = _native.load()
     sd = synthetic.make_state_dict(0)

@@ -105,3 +105,17 @@ def test_precision_is_a_constructor_argument_not_an_environment_variable(monkeyp
         GATsSuperGlue(HP, "bf16x3")        # keyword-only: the positional signature stays the reference's
     # same parameters in both modes: a reference state_dict loads strictly
     b.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(0).items()}, strict=True)
+
+
+def test_hip_queue_pool_is_configured_before_the_runtime_starts(monkeypatch):
+    """runtime.configure_hip_queues: a caller's GPU_MAX_HW_QUEUES wins; unset -> 8 (one queue per frame in flight)."""
+    import os
+    from onepose_amd import runtime
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "5")
+    assert runtime.configure_hip_queues() == "5" and os.environ["GPU_MAX_HW_QUEUES"] == "5"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    assert runtime.configure_hip_queues() == str(runtime.HW_QUEUES) and os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    assert runtime.FRAMES_IN_FLIGHT == 4
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            runtime.StreamRing("cpu")
