@@ -697,8 +697,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--reps", type=int, default=5, help="the K-step timed pass is repeated this many times; the median is reported")
-    ap.add_argument("--streams", type=int, default=4, help="query frames kept in flight per GPU (one HIP stream each; needs "
-                                                             "GPU_MAX_HW_QUEUES > streams, set to 8 at the top of this file)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="query frames kept in flight per GPU (one HIP stream each).  Default: 4 when the runtime's queue pool gives every "
+                         "stream and the null stream a hardware queue of its own (GPU_MAX_HW_QUEUES >= 5; this file exports 8 unless the "
+                         "caller set it), else 3 (the optimum on the default pool of 4, DESIGN 14k)")
     ap.add_argument("--config", default="headline", choices=list(CONFIGS),
                     help="workload: 'headline' = BASELINE configs[1] (the value the driver records); the others are "
                          "separately reported lines (config.workload names them)")
@@ -728,6 +730,12 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: stub steps on CPU over gloo -- tests the --gpus N launcher, barrier, metrics gather and JSON line")
     args = ap.parse_args()
+    if args.streams <= 0:
+        try:
+            pool = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        except ValueError:
+            pool = 4
+        args.streams = 4 if pool >= 5 else 3
     if args.tuning_lib:
         from onepose_amd import build_ext
         _native.LIB_PATH = build_ext.tuning_path(build_ext.LIB_PATH)
@@ -758,7 +766,7 @@ def main():
         dims = [int(v) for v in args.shape.split(",")]
         cfg = dict(cfg, n1=dims[0], n2=dims[1], b=dims[2] if len(dims) > 2 else cfg["b"], golden=None,
                    what=f"CUSTOM SHAPE (tuning run, not a BASELINE config): N_2D={dims[0]} N_3D={dims[1]}, arithmetic of '{args.config}'")
-    K, W, S, R = args.steps, args.warmup, max(1, args.streams), max(1, args.reps)
+    K, W, S, R = args.steps, args.warmup, max(1, args.streams), max(1, args.reps)   # (args.streams resolved in main())
 
     if args.dry_run:
         device = None
