@@ -76,38 +76,74 @@ def make_passthrough_state_dict(seed=0):
     return sd
 
 
+TRAINED_BASE_SEED = 21
+
+
+def make_trained_state_dict(path=None):
+    """TRAINED weights (round 5; tests/golden/make_trained_golden.py): the random-init state dict of seed 21 plus a
+    rank-8 update of every weight matrix on the forward path and a full update of every bias, obtained by training the
+    REFERENCE module with the reference's focal loss on planted synthetic frames (every AttentionPropagation delta and
+    final_proj active -- nothing zeroed, unlike the pass-through fixture).  Only the factors are committed (~1 MB):
+    `W = W_init + sum_k U[:, k] V[:, k]^T`, accumulated rank by rank in float64 with elementwise numpy ops (no BLAS: the
+    summation order is fixed, so the container that ran the reference and the GPU box rebuild the same fp32 bits)."""
+    import os
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "trained_lowrank.npz")
+    fac = np.load(path)
+    sd = make_state_dict(TRAINED_BASE_SEED)
+    for key in fac.files:
+        kind, name = key.split("::", 1)
+        if kind == "B":
+            sd[name] = (sd[name].astype(np.float64) + fac[key].astype(np.float64)).astype(np.float32)
+        elif kind == "U":
+            u, v = fac[key].astype(np.float64), fac["V::" + name].astype(np.float64)
+            w = sd[name]
+            acc = w.reshape(w.shape[0], -1).astype(np.float64)
+            for k in range(u.shape[1]):
+                acc = acc + u[:, k:k + 1] * v[None, :, k]
+            sd[name] = acc.astype(np.float32).reshape(w.shape)
+    return sd
+
+
 def _unit(x, axis):
     return (x / np.linalg.norm(x, axis=axis, keepdims=True)).astype(np.float32)
 
 
-def make_inputs(b, n1, n2, num_leaf=8, seed=1, planted=False):
+def make_inputs(b, n1, n2, num_leaf=8, seed=1, planted=False, noise=(0.2, 0.3), with_targets=False):
     """Synthetic forward() inputs (keys of GATs_SuperGlue.py:181-189).
 
     planted=False: independent unit-norm random descriptors (benchmark distribution).
     planted=True (fixture B): leaves are noisy copies (noise norm ~0.2) of their 3D descriptor and
     the first n1//2 query descriptors are noisy copies (noise norm ~0.3) of distinct random 3D
-    descriptors, so well-separated ground-truth matches exist.
+    descriptors, so well-separated ground-truth matches exist.  `noise` = (leaf, query) noise norms.
+    with_targets=True additionally returns the planted ground truth `[b, k]` (query i of sample bi matches
+    3D point targets[bi, i]); the dict itself never changes.
     """
     rs = np.random.RandomState(seed)
+    targets = []
     d3 = _unit(rs.standard_normal((b, D, n2)), 1)
     if planted:
-        leaves = np.repeat(d3, num_leaf, axis=2) + 0.2 * rs.standard_normal((b, D, n2 * num_leaf)) / np.sqrt(D)
+        leaves = np.repeat(d3, num_leaf, axis=2) + noise[0] * rs.standard_normal((b, D, n2 * num_leaf)) / np.sqrt(D)
         d2db = _unit(leaves, 1)
         dq = _unit(rs.standard_normal((b, D, n1)), 1)
         k = min(n1 // 2, n2)
         for bi in range(b):
             tgt = rs.permutation(n2)[:k]
-            dq[bi, :, :k] = _unit(d3[bi][:, tgt] + 0.3 * rs.standard_normal((D, k)) / np.sqrt(D), 0)
+            dq[bi, :, :k] = _unit(d3[bi][:, tgt] + noise[1] * rs.standard_normal((D, k)) / np.sqrt(D), 0)
+            targets.append(tgt)
     else:
         d2db = _unit(rs.standard_normal((b, D, n2 * num_leaf)), 1)
         dq = _unit(rs.standard_normal((b, D, n1)), 1)
-    return {
+    data = {
         "keypoints2d": (rs.rand(b, n1, 2) * 512).astype(np.float32),
         "keypoints3d": (rs.rand(b, n2, 3) - 0.5).astype(np.float32),
         "descriptors2d_query": dq,
         "descriptors3d_db": d3,
         "descriptors2d_db": d2db,
     }
+    if with_targets:
+        return data, (np.stack(targets) if targets else np.zeros((b, 0), np.int64))
+    return data
 
 
 # ---- SuperPoint extractor (src/models/extractors/SuperPoint/superpoint.py:115-133) ---------------

@@ -32,8 +32,15 @@ def case_inputs(meta_case):
     """Rebuild (state_dict, inputs, hparams) of a golden case from its seeds."""
     from onepose_amd import synthetic
     kind, seed = meta_case["weights"]
-    sd = synthetic.make_state_dict(seed) if kind == "random" else synthetic.make_passthrough_state_dict(seed)
-    data = synthetic.make_inputs(**meta_case["inputs"])
+    if kind == "trained":     # tests/golden/make_trained_golden.py: the reference module trained with the reference loss
+        assert seed == synthetic.TRAINED_BASE_SEED
+        sd = synthetic.make_trained_state_dict()
+    else:
+        sd = synthetic.make_state_dict(seed) if kind == "random" else synthetic.make_passthrough_state_dict(seed)
+    inputs = dict(meta_case["inputs"])
+    if "noise" in inputs:
+        inputs["noise"] = tuple(inputs["noise"])
+    data = synthetic.make_inputs(**inputs)
     return sd, data, meta_case["hparams"]
 
 
@@ -41,6 +48,15 @@ def case_inputs(meta_case):
 def bench_golden_meta():
     with open(os.path.join(GOLDEN_DIR, "bench_golden_meta.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def trained_golden_meta():
+    with open(os.path.join(GOLDEN_DIR, "trained_golden_meta.json")) as f:
+        return json.load(f)
+
+
+TRAINED_CASES = ["trained_small", "trained_real", "trained_head", "trained_hard"]
 
 
 # An arg-max may differ from the reference's only where the two candidates are closer than the arithmetic can resolve:

@@ -118,3 +118,39 @@ def test_oracle_matches_reference_at_benchmarked_shapes(name, bench_golden_meta)
     res = check_bench_golden(conf, pred, g, mc, 5e-6, name, rsum_rtol=1e-4)   # conf up to 0.99: a few fp32 ulps
     print(name, res)
     assert res["flips_rows"] + res["flips_cols"] == 0
+
+
+@pytest.mark.parametrize("name", ["trained_small", "trained_real", "trained_head", "trained_hard"])
+def test_oracle_matches_reference_on_trained_weights(name, trained_golden_meta):
+    """The oracle against the reference run on TRAINED weights (tests/golden/make_trained_golden.py: the reference module
+    trained with the reference focal loss until the full 12-layer network recovers planted matches; conf of the true pairs
+    0.002 ... 0.99, i.e. O(1) values with every AttentionPropagation delta and final_proj active)."""
+    from conftest import check_bench_golden
+    mc = trained_golden_meta["cases"][name]
+    g = load_golden(name)
+    sd, data, hp = case_inputs(mc)
+    pred, conf = orc.forward(sd, data, hp)
+    res = check_bench_golden(conf, pred, g, mc, 5e-6, name, rsum_rtol=1e-4)
+    tg = g["planted_targets"]
+    planted = np.stack([conf[bi, np.arange(tg.shape[1]), tg[bi]] for bi in range(conf.shape[0])])
+    np.testing.assert_allclose(planted, g["conf_planted"], atol=5e-6)
+    if "conf" in g:
+        np.testing.assert_allclose(conf, g["conf"], atol=5e-6)
+    print(name, res, "conf of the planted pairs", float(planted.min()), "...", float(planted.max()))
+    assert res["flips_rows"] + res["flips_cols"] == 0
+    assert float(planted.max()) > 0.9 and mc["planted_recovered_sample0"] >= 0.9 * mc["planted"]
+
+
+def test_trained_weights_are_a_full_network():
+    """Nothing on the forward path is zeroed or an identity (unlike the pass-through fixture), and every weight moved."""
+    from onepose_amd import synthetic
+    sd, base = synthetic.make_trained_state_dict(), synthetic.make_state_dict(synthetic.TRAINED_BASE_SEED)
+    for k, v in sd.items():
+        assert v.dtype == np.float32 and v.shape == base[k].shape
+        if k.startswith("kenc") or k == "bin_score":
+            np.testing.assert_array_equal(v, base[k])       # never reach forward (GATs_SuperGlue.py:179-241)
+        else:
+            assert np.abs(v - base[k]).max() > 0, k
+    for i in synthetic.ATTN_LAYERS:
+        assert np.abs(sd[f"gnn.layers.{i}.mlp.3.weight"]).max() > 0.01
+    assert np.abs(sd["final_proj.weight"][:, :, 0] - np.eye(256)).max() > 0.05
