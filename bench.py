@@ -112,10 +112,11 @@ def roofline_floors(n1, n2, precision):
 
 
 class Weights:
-    """Random-init GATsSPG weights packed once on the device (shared by every in-flight frame)."""
+    """GATsSPG weights (random init; `--config trained`: trained) packed once on the device (shared by every in-flight frame)."""
 
-    def __init__(self, device, precision="fp32"):
-        sd = synthetic.make_state_dict(0)
+    def __init__(self, device, precision="fp32", kind="random"):
+        # kind "trained": the reference module trained with the reference focal loss (tests/golden/make_trained_golden.py)
+        sd = synthetic.make_trained_state_dict() if kind == "trained" else synthetic.make_state_dict(0)
         self.model = GATsSuperGlue(HP, precision=precision).eval()
         self.model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
         self.model.to(device)
@@ -129,7 +130,7 @@ class Runner:
     pre-allocated; step() is a single C-ABI call that enqueues one forward on the slot's stream."""
 
     def __init__(self, device, weights, shared_inputs=None, b=1, n1=N1, n2=N2, n_query_frames=4, own_stream=False,
-                 golden_seed=None):
+                 golden_seed=None, golden_inputs=None):
         self.device = device
         self.b, self.n1, self.n2 = b, n1, n2
         if shared_inputs is None:
@@ -137,7 +138,10 @@ class Runner:
             # frames (inference.py:113-130); query descriptors rotate over a small pool of frames.  The database and pool
             # slot 0 are the inputs of the reference-run golden of this shape (golden_seed), so the line can carry a parity
             # number against the reference's own output; the other slots are fresh random unit-norm frames.
-            data = synthetic.make_inputs(b, n1, n2, NUM_LEAF, seed=1 if golden_seed is None else golden_seed)
+            if golden_inputs is not None:   # a golden with its own input recipe (planted frames of the trained-weights goldens)
+                data = synthetic.make_inputs(**dict(golden_inputs, noise=tuple(golden_inputs.get("noise", (0.2, 0.3)))))
+            else:
+                data = synthetic.make_inputs(b, n1, n2, NUM_LEAF, seed=1 if golden_seed is None else golden_seed)
             d3 = torch.from_numpy(data["descriptors3d_db"]).to(device)
             d2db = torch.from_numpy(data["descriptors2d_db"]).to(device)
             rs = np.random.RandomState(7)
@@ -617,6 +621,15 @@ CONFIGS = {
                              "split-fp16 MFMA; reported separately, never the headline value"),
     "fp16x4-real-b8": dict(b=8, n1=500, n2=2000, precision="fp16x4", golden="real_b8",
                            what="8 frames of 500/2000 per step, attention-layer GEMMs on four-term split-fp16 MFMA; reported separately"),
+    "trained": dict(b=1, n1=1000, n2=7000, precision="fp32", golden="trained_head", weights="trained",
+                    what="headline shape (1000/7000, batch 1), fp32, on TRAINED weights (the reference module trained with the reference focal "
+                         "loss on planted frames, tests/golden/make_trained_golden.py): the parity_check compares conf values of O(1) "
+                         "(0.56 ... 0.95 on the 500 planted pairs) and the thresholded matches with the reference's; same kernels, same speed "
+                         "as the headline line; reported separately"),
+    "fp16x4-trained": dict(b=1, n1=1000, n2=7000, precision="fp16x4", golden="trained_head", weights="trained",
+                           what="the trained-weights workload with the attention-layer GEMMs on four-term split-fp16 MFMA; reported separately"),
+    "trained-hard": dict(b=1, n1=1000, n2=7000, precision="fp32", golden="trained_hard", weights="trained",
+                         what="trained weights, noisier planted frames (conf of the true pairs 0.002 ... 0.91, the 0.2 threshold cuts through them)"),
 }
 GOLDEN_SEEDS = {"head_rand": 1, "head_b8": 3, "stress_rand": 5, "stress_b4": 7, "real_rand": 8, "real_b8": 9}   # make_inputs seeds of tests/golden/make_bench_golden.py
 
@@ -625,11 +638,13 @@ def golden_parity(runner, cfg):
     """One forward of the golden's inputs on the timed code path, compared with the REFERENCE's outputs committed under
     tests/golden/ (conf sub-sample, row/col maxima, raw arg-max indices).  No oracle involved."""
     name = cfg["golden"]
-    path = os.path.join(ROOT, "tests", "golden", f"bench_{name}.npz")
+    trained = cfg.get("weights") == "trained"
+    fname = f"{name}.npz" if trained else f"bench_{name}.npz"
+    path = os.path.join(ROOT, "tests", "golden", fname)
     if name is None or not os.path.exists(path):
         return None
     g = np.load(path)
-    with open(os.path.join(ROOT, "tests", "golden", "bench_golden_meta.json")) as f:
+    with open(os.path.join(ROOT, "tests", "golden", "trained_golden_meta.json" if trained else "bench_golden_meta.json")) as f:
         sub = json.load(f)["cases"][name]["sub"]
     with torch.cuda.stream(runner.stream):
         runner.step(0)                     # pool slot 0 = the golden's query frame(s)
@@ -638,8 +653,19 @@ def golden_parity(runner, cfg):
     err = max(float(np.abs(c[:, ::sub[0], ::sub[1]] - g["conf_sub"]).max()), float(np.abs(c.max(2) - g["conf_rowmax"]).max()),
               float(np.abs(c.max(1) - g["conf_colmax"]).max()))
     flips = int((c.argmax(2) != g["indices0_raw"]).sum() + (c.argmax(1) != g["indices1_raw"]).sum())
-    return {"against": f"tests/golden/bench_{name}.npz (reference GATsSuperGlue.forward run on CPU fp32, same seeded inputs)",
-            "max_abs_conf_err": err, "argmax_flips": flips, "argmax_checked": int(c.shape[0] * (c.shape[1] + c.shape[2]))}
+    out = {"against": f"tests/golden/{fname} (reference GATsSuperGlue.forward run on CPU fp32, same seeded inputs)",
+           "max_abs_conf_err": err, "argmax_flips": flips, "argmax_checked": int(c.shape[0] * (c.shape[1] + c.shape[2]))}
+    if trained:   # conf values of O(1) and the thresholded matches (match_threshold 0.2) against the reference's
+        tg = g["planted_targets"]
+        planted = np.stack([c[bi, np.arange(tg.shape[1]), tg[bi]] for bi in range(c.shape[0])])
+        m0, m1 = runner.m0[0].cpu().numpy(), runner.m1[0].cpu().numpy()
+        out.update({"weights": "trained (reference module + reference FocalLoss, tests/golden/make_trained_golden.py)",
+                    "conf_of_planted_pairs_min_max": [float(planted.min()), float(planted.max())],
+                    "max_abs_conf_err_on_planted_pairs": float(np.abs(planted - g["conf_planted"]).max()),
+                    "matches0_differing_from_reference": int((m0 != g["matches0"]).sum()),
+                    "matches1_differing_from_reference": int((m1 != g["matches1"]).sum()),
+                    "valid_matches0": int((m0 >= 0).sum())})
+    return out
 
 
 def side_arithmetic(device, cfg, precision, shared_inputs, K, W, S):
@@ -685,7 +711,8 @@ def self_launch(args, argv):
 class DryRunner:
     """CPU stand-in for a frame slot (bench.py --dry-run): exercises the launcher / barrier / metrics-gather / JSON path
     without a GPU.  Never produces a benchmark number (the line says data: "dry-run")."""
-    b = 1
+    def __init__(self, b=1):
+        self.b = b
 
     def step(self, i):
         time.sleep(0.002)
@@ -770,7 +797,7 @@ def main():
 
     if args.dry_run:
         device = None
-        slots = [DryRunner() for _ in range(S)]
+        slots = [DryRunner(cfg["b"]) for _ in range(S)]
         sync = lambda: None  # noqa: E731
     else:
         if not torch.cuda.is_available():
@@ -781,8 +808,13 @@ def main():
         torch.cuda.set_device(device)
         if launched:   # one launch thread per rank, next to its GPU (N Python loops at ~60 k launches/s each are host-sensitive)
             pinned, prev_affinity = sharding.pin_launch_thread(device)
-        weights = Weights(device, cfg["precision"])
-        base = Runner(device, weights, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], golden_seed=GOLDEN_SEEDS.get(cfg["golden"]))
+        weights = Weights(device, cfg["precision"], cfg.get("weights", "random"))
+        golden_inputs = None
+        if cfg.get("weights") == "trained" and cfg["golden"]:
+            with open(os.path.join(ROOT, "tests", "golden", "trained_golden_meta.json")) as f:
+                golden_inputs = json.load(f)["cases"][cfg["golden"]]["inputs"]
+        base = Runner(device, weights, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], golden_seed=GOLDEN_SEEDS.get(cfg["golden"]),
+                      golden_inputs=golden_inputs)
         slots = [Runner(device, weights, base.shared_inputs, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], own_stream=True) for _ in range(S)]
         sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
     sync()
@@ -809,13 +841,14 @@ def main():
 
     dev_key, dev_desc = sharding.device_identity(device)
     if args.dry_run:
-        per_rank = sharding.gather_metrics([K, elapsed, dev_key])
+        per_rank = sharding.gather_metrics([K * cfg["b"], elapsed, dev_key])
         value, seconds = sharding.aggregate_throughput(per_rank)
         if rank == 0:
             print(json.dumps({"metric": "query_frames_per_sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
                               "steps": K, "warmup": W, "ms_per_step": round(seconds / K * 1e3, 4), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run",
-                              "config": {"workload": "DRY RUN: stub steps on CPU, launcher / collective plumbing only",
+                              "config": {"workload": "DRY RUN: stub steps on CPU, launcher / collective plumbing only", "name": args.config,
+                                         "frames_per_step_per_gpu": cfg["b"], "frames_per_step_all_gpus": cfg["b"] * world,
                                          "per_rank_frames_per_sec": [round(float(k / t), 2) for k, t, _ in per_rank.tolist()],
                                          "ranks_seen": len({int(d) for _, _, d in per_rank.tolist()}),
                                          "rank_devices": [int(d) for _, _, d in per_rank.tolist()]}}), flush=True)
@@ -882,6 +915,21 @@ def main():
                      "note": "3D database resident, its query-independent GNN work cached once per object; bit-identical outputs"}
 
     parity = golden_parity(runner, cfg) if rank == 0 else None
+    # the same check on TRAINED weights (conf values of O(1), thresholded matches): one extra forward per arithmetic after the timed
+    # region, headline line only (the timed workload stays BASELINE configs[1]: random-init weights, random descriptors)
+    parity_trained = None
+    if rank == 0 and world == 1 and args.config == "headline" and not args.shape and not args.no_side_arithmetics:
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "trained_golden_meta.json")) as f:
+                gi = json.load(f)["cases"]["trained_head"]["inputs"]
+            parity_trained = {}
+            for prec in ("fp32", "fp16x4"):
+                tcfg = CONFIGS["trained" if prec == "fp32" else "fp16x4-trained"]
+                tr = Runner(device, Weights(device, prec, "trained"), b=1, n1=tcfg["n1"], n2=tcfg["n2"], golden_inputs=gi)
+                parity_trained[prec] = golden_parity(tr, tcfg)
+                del tr
+        except FileNotFoundError:
+            parity_trained = None
     # the one (RCCL) collective: timings + the identity key of the device each rank drives (float64: keys are exact integers)
     per_rank = sharding.gather_metrics([K * runner.b, elapsed, solo if solo is not None else elapsed, dev_key], device=device)
     value, seconds = sharding.aggregate_throughput(per_rank.cpu())
@@ -913,6 +961,7 @@ def main():
                        + ("the score contraction of the dual softmax on the same split arithmetic (fp32-class modes only); final_proj, GATs, "
                           "the KV pass and every reduction fp32" if cfg["precision"] in ("bf16x6", "fp16x4") else "final_proj, score, GATs fp32"),
                        "n_2d": n1, "n_3d": n2, "num_leaf": NUM_LEAF, "batch": bsz, "steps_per_gpu": K, "frames_per_gpu": K * bsz,
+                       "frames_per_step_per_gpu": bsz, "frames_per_step_all_gpus": bsz * world,
                        "frames_in_flight_per_gpu": S * bsz, "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "timed_pass_repetitions": R,
                        "timed_pass_seconds": [round(t, 5) for t in reps], "reported": "median repetition",
@@ -954,6 +1003,8 @@ def main():
             out["config"]["tuning_build"] = {k: v for k, v in os.environ.items() if k.startswith(("GATSSPG_", "SPP_"))}
         if parity:
             out["parity_check"] = parity
+        if parity_trained:
+            out["parity_check_trained_weights"] = parity_trained
         if amortised:
             out["amortised_database_mode"] = amortised
         if side:

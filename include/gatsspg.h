@@ -51,7 +51,9 @@ extern "C" {
  *     mantissa bits) and each product the six largest of the nine term products; what is dropped is <= 2^-24 |ab|, one
  *     fp32 rounding of the product, and the accumulation is the MFMA's fp32 accumulation -- fp32-class arithmetic on the
  *     bf16 matrix pipe (the tests hold it to the fp32 mode's own tie-gap tolerance).  The two precision bits are exclusive.
- * final_proj, the score contraction, GATs and all reductions are fp32 in every mode. */
+ * final_proj, GATs, the KV pass of the linear attention and all reductions are fp32 in every mode; the score contraction of the dual
+ * softmax is fp32 in the three-term modes (BF16X3, FP16X3) and runs on the same split arithmetic as the GEMMs in the fp32-class
+ * modes (BF16X6, FP16X4: score_exp_sp_kernel, exact products of the split unit-norm descriptors). */
 #define GATSSPG_FLAG_PREC_BF16X3 0x100
 #define GATSSPG_FLAG_PREC_BF16X6 0x200
 /*   GATSSPG_FLAG_PREC_FP16X3 / _FP16X4: two-term split on IEEE fp16 -- every fp32 operand is x1 + x2 with x1 = RNE_fp16(x),
@@ -60,8 +62,10 @@ extern "C" {
  *     multiplied by an EXACT power of two before the split and the accumulators are scaled back (ABI 400), so that the second term
  *     stays a normal fp16 number for small operands: weights per matrix at pack time (largest entry to [2^13, 2^14): the 2^-23
  *     bound holds down to |w| ~ 2^-24 max|W|), activations by 2^4 (bound holds down to |x| ~ 2^-7, absolute error 2^-29 below;
- *     exact two-term range +-8188, saturating beyond), the per-segment message operator by 2^-(ceil(log2 n_source) + 6) of its
- *     weight scale (its entries grow with the number of source points).
+ *     exact two-term range +-8188, saturating beyond), the message operator M_h of every (segment, head) by a power of two taken from a
+ *     RIGOROUS bound of its entries, |M_h| <= (largest row-L1 norm of head h's merge-folded mlp.0 half) * n_source * max K_h * max |V_h|,
+ *     with the two data maxima carried by the KV partials (ABI 410; the ABI-400 form, 2^-(ceil(log2 n_source) + 6) of the weight
+ *     scale, never looked at the data and could saturate silently on large message weights or a large mean of V).
  *     FP16X3: the three leading products on v_mfma_f32_32x32x16_f16 -- the matrix-pipe time of bf16x3 (BASELINE configs[3] names
  *     fp16; a SINGLE fp16 term fails the parity bar like a single bf16 term does).  FP16X4: all four products, the exact product
  *     of the split operands with fp32 accumulation -- fp32-class results in four MFMAs where bf16x6 needs six.  Measured parity in

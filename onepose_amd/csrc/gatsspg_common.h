@@ -12,7 +12,8 @@ constexpr int H = 4;      // heads (GATs_SuperGlue.py:43)
 constexpr int DH = 64;    // channels per head
 constexpr int CP = 128;   // column padding granule: every (frame, side) segment starts on a multiple of CP
 constexpr int BK = 32;    // K tile of every MFMA GEMM
-constexpr int KVP = DH * DH + DH;  // one KV partial: the 64x64 KV matrix TRANSPOSED, [d][q] (kv_final owns 4-row d blocks), + 64 ksum
+constexpr int KVMAX = 8;           // operand maxima of a KV partial (fp16 modes): [0..3] max K, [4..7] max |V| of the tile, one slot per wave
+constexpr int KVP = DH * DH + DH + KVMAX;  // one KV partial: the 64x64 KV matrix TRANSPOSED, [d][q] (kv_final owns 4-row d blocks), + 64 ksum + maxima
 constexpr int MOP_LD = 512;        // row stride of the per-segment message operators M_seg [512][256] (two segments share a [512][512] block)
 constexpr int MPL_PLANE = 512 * 256;   // bf16 elements of one split plane of M_seg (slab-major like the weight planes)
 
@@ -83,10 +84,11 @@ struct AttnW {  // offsets inside one attention layer block
     static constexpr size_t B0 = W0 + 512 * 512;               // [512] = b0 + W0b @ bm
     static constexpr size_t W3 = B0 + 512;                     // [256][512]
     static constexpr size_t B3 = W3 + 256 * 512;               // [256]
-    // [4]: the exact powers of two the fp16 planes of WQKV, W0[:, :256] and W3 are multiplied by before the split (weight_scale_kernel:
-    // the matrix maximum lands in [2^13, 2^14)); [3] spare.  The consumers scale the accumulators back.
+    // [8]: [0..2] the exact powers of two the fp16 planes of WQKV, W0[:, :256] and W3 are multiplied by before the split
+    // (weight_scale_kernel: the matrix maximum lands in [2^13, 2^14)); [3] spare; [4 + h] = max_r sum_q |(W0b Wm)[r][h*64 + q]|, the
+    // row-L1 norm of head h's message half: kv_final bounds the operator M_h with it.  The consumers scale the accumulators back.
     static constexpr size_t SC = B3 + 256;
-    static constexpr size_t SIZE = SC + 4;
+    static constexpr size_t SIZE = SC + 8;
 };
 struct GatsW {
     static constexpr size_t U1 = 0;              // [256] = W @ a[:256]   (leaf logit vector)
@@ -145,7 +147,7 @@ struct Workspace {
     float *Mop;                      // [b][512][512]: segment 2f at columns 256..511, segment 2f+1 at columns 0..255 of frame f's block
     unsigned short *Mpl;             // split-bf16 planes of M_t (prec != 0): [nseg][3][8 slabs][512][32]
     float *ksumT;                    // [nseg][4][64]
-    float *zsc;                      // [nseg]: fold factor of the target segment's operator planes = (scale of the W0 planes) / (scale of Mpl), a power of two
+    float *zsc;                      // [nseg][4]: per head, fold factor of the target segment's operator planes = (scale of the W0 planes) / (scale of Mpl_h), a power of two
     float *rowpart, *colpart, *rs, *cs;
     float *rmax_v, *cmax_v, *rshift, *cshift;   // rshift / cshift: row / column maxima of the max-subtracting dual softmax
     int *rmax_i, *cmax_i;
@@ -187,7 +189,7 @@ inline Workspace carve_workspace(void* base, int b, int n1, int n2) {
     w.Mop = (float*)take(sizeof(float) * (size_t)b * 512 * MOP_LD);
     w.Mpl = (unsigned short*)take(sizeof(unsigned short) * (size_t)w.nseg * 3 * MPL_PLANE);
     w.ksumT = (float*)take(sizeof(float) * (size_t)w.nseg * H * DH);
-    w.zsc = (float*)take(sizeof(float) * (size_t)w.nseg);
+    w.zsc = (float*)take(sizeof(float) * (size_t)w.nseg * H);
     w.statpart = (float*)take(sizeof(float) * (size_t)w.nt64 * 2 * 512);
     w.stats = (float*)take(sizeof(float) * (size_t)w.nseg * 2 * 512);
     w.statcnt = (int*)take(sizeof(int) * (size_t)w.nseg * 8);

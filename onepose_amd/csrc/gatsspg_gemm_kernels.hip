@@ -191,6 +191,7 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
                                                         const float* __restrict__ sc, ColLayout L, int cross, int prec, int abl) {
     __shared__ float4 red[16][64];
     __shared__ float4 kvs[64];   // this block's final KV^T rows: [4 d][16 float4 of q]
+    __shared__ float opmax[2][16];   // fp16 modes: per-wave maxima of K and |V| over the source segment's tiles
     constexpr int KVF_ROWS = 512 / KVF_RS;
     if (prec >= 3) fp16_saturate_mode();
     const int tid = threadIdx.x;
@@ -202,12 +203,16 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
     const int frame = seg >> 1, side = seg & 1;
     if (!((L.side_mask >> side) & 1)) return;
     const int tseg = cross ? (seg ^ 1) : seg;
-    // fp16 modes: the operator planes hold sM * M, sM = (scale of the W0 planes) * 2^-(ceil(log2 n_src) + 6): KV sums grow with the
-    // number of source points (the reference's v / n ... * n pair cancels, GATs_SuperGlue.py:74-79), unscaled they leave the fp16 range
-    // beyond a few thousand points.  mlp0 folds heads with z_h * zsc, zsc = (W0 scale) / sM = 2^(ceil(log2 n_src) + 6): exact.
+    // fp16 modes: the operator planes of head h hold sM_h * M_h with a power of two sM_h chosen from a RIGOROUS bound of the operator's
+    // entries (round-4 advisor: the former 2^-(ceil(log2 n_src) + 6) heuristic never looked at the data and could saturate silently):
+    //     |M_h[r][d]| = |sum_q (W0b Wm)[r][h, q] KV_h[q][d]| <= l1_h * max |KV_h|,   |KV_h[q][d]| = |sum_m V[q][m] K[d][m]| <= n_src * vmax_h * kmax_h
+    // l1_h = largest row-L1 norm of head h's message half (pack time, AttnW::SC[4 + h]); kmax_h / vmax_h = largest K / |V| entry of the
+    // source segment, carried by the KV partials (qkv_kv_sp_kernel) and maximised here by every block -- same loads, same order, same
+    // result in every block of a (segment, head).  sM_h = 2^(14 - e), 2^e > bound: no entry reaches 2^14 (fp16 maximum 65504).  The
+    // bound is loose by the random-sign cancellation of the two sums (typically 2^8 .. 2^13): the largest entries then sit around
+    // 2^1 .. 2^6, where both fp16 terms are still normal numbers (relative error 2^-22); an entry 2^-6 below them keeps 2^-21.
+    // mlp0 folds head h with z_h * zsc_h, zsc_h = (W0 scale) / sM_h: exact.
     const int nsrc = side ? L.n2 : L.n1;
-    const int mexp = (32 - __clz(max(nsrc, 2) - 1)) + 6;
-    const float mscale = prec >= 3 ? sc[1] * __builtin_ldexpf(1.f, -mexp) : 1.f;
     // operator phase: thread = (row pair rp, q quarter qq); lane qq takes the float4s qq, qq + 4, qq + 8, qq + 12 of the 64 q of a
     // row (the 4 lanes of a row read 64 contiguous bytes per load).  The weights do not depend on the reduction: requested first.
     const int rp = (tid >> 2) & (KVF_ROWS / 2 - 1), qq = tid & 3;
@@ -232,6 +237,17 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
     const int nt = cached ? 1 : (side ? L.n2p : L.n1p) / QKV_BN;
     const int per = (nt + 15) / 16;
     const int tb = part * per, te = min(nt, tb + per);
+    // operand maxima of the source's tiles (fp16 modes; requested in front of the reduction's loads, consumed behind them)
+    constexpr int MAX4 = (DH * DH + DH) / 4;   // float4 index of a partial's maxima: [max K x 4 waves][max |V| x 4 waves]
+    float kmx = 0.f, vmx = 0.f;
+    if (prec >= 3)
+        for (int t = tid; t < nt; t += 1024) {
+            const float4* mp = reinterpret_cast<const float4*>(base + (size_t)t * H * KVP) + MAX4;
+            const float4 a = mp[0], b4 = mp[1];
+            kmx = fmaxf(kmx, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+            vmx = fmaxf(vmx, fmaxf(fmaxf(b4.x, b4.y), fmaxf(b4.z, b4.w)));
+        }
+    const bool ismax = e4 >= MAX4;   // the maxima elements are combined with max, everything else is summed
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int tt = tb; tt < te; tt += 8) {
         float4 x[8];
@@ -240,23 +256,48 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
             x[u] = *reinterpret_cast<const float4*>(base + (size_t)min(tt + u, nt - 1) * H * KVP + 4 * e4);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (tt + u < te) { s.x += x[u].x; s.y += x[u].y; s.z += x[u].z; s.w += x[u].w; }
+            if (tt + u < te) {
+                s.x = ismax ? fmaxf(s.x, x[u].x) : s.x + x[u].x; s.y = ismax ? fmaxf(s.y, x[u].y) : s.y + x[u].y;
+                s.z = ismax ? fmaxf(s.z, x[u].z) : s.z + x[u].z; s.w = ismax ? fmaxf(s.w, x[u].w) : s.w + x[u].w;
+            }
     }
     red[part][el] = s;
+    if (prec >= 3) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            kmx = fmaxf(kmx, __shfl_xor(kmx, o));
+            vmx = fmaxf(vmx, __shfl_xor(vmx, o));
+        }
+        if (el == 0) { opmax[0][part] = kmx; opmax[1][part] = vmx; }
+    }
     __syncthreads();
+    float mscale = 1.f, zfold = 1.f;
+    if (prec >= 3) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            kmx = fmaxf(kmx, opmax[0][p]);
+            vmx = fmaxf(vmx, opmax[1][p]);
+        }
+        const float bound = sc[4 + h] * (float)nsrc * kmx * vmx;
+        int e = 0;
+        if (bound > 0.f && bound < 3.0e38f) e = min(max(ilogbf(bound) + 1, -100), 100);   // 2^e > bound
+        mscale = __builtin_ldexpf(1.f, 14 - e);
+        zfold = sc[1] / mscale;
+    }
     if (part == 0) {
         float4 tot = red[0][el];
 #pragma unroll
         for (int p = 1; p < 16; ++p) {
             const float4 r = red[p][el];
-            tot.x += r.x; tot.y += r.y; tot.z += r.z; tot.w += r.w;
+            tot.x = ismax ? fmaxf(tot.x, r.x) : tot.x + r.x; tot.y = ismax ? fmaxf(tot.y, r.y) : tot.y + r.y;
+            tot.z = ismax ? fmaxf(tot.z, r.z) : tot.z + r.z; tot.w = ismax ? fmaxf(tot.w, r.w) : tot.w + r.w;
         }
         kvs[el] = tot;
         if (db * 64 + el < KVP4 && rs == 0) {
             *reinterpret_cast<float4*>(kvfin + ((size_t)seg * H + h) * KVP + 4 * e4) = tot;
             if (ksum_block) {
-                *reinterpret_cast<float4*>(ksumT + ((size_t)tseg * H + h) * DH + 4 * el) = tot;   // ksum of the source
-                if (h == 0 && el == 0) zsc[tseg] = prec >= 3 ? __builtin_ldexpf(1.f, mexp) : 1.f;
+                if (el < DH / 4) *reinterpret_cast<float4*>(ksumT + ((size_t)tseg * H + h) * DH + 4 * el) = tot;   // ksum of the source
+                if (el == 0) zsc[tseg * H + h] = zfold;
                 // arrival counters of the target segment's fused InstanceNorm statistics (mlp.0 is enqueued behind this launch)
                 if (h == 0 && el < STATCNT_PER_SEG) statcnt[tseg * STATCNT_PER_SEG + el] = 0;
             }
@@ -877,6 +918,23 @@ __global__ __launch_bounds__(1024) void weight_scale_kernel(float* __restrict__ 
         if (top > 0.f && top < 3.0e38f) e = min(max(13 - ilogbf(top), -40), 60);
         blk[AttnW::SC + m] = __builtin_ldexpf(1.f, e);
         if (m == 0) blk[AttnW::SC + 3] = 1.f;
+    }
+    if (m == 1) {   // row-L1 norms of the message half per head (AttnW::SC[4 + h]): |M_h[r][d]| <= l1_h * max |KV_h| (kv_final_kernel)
+        for (int h = 0; h < H; ++h) {
+            __syncthreads();
+            float l1 = 0.f;
+            if (threadIdx.x < 512) {
+                const float* wr = blk + AttnW::W0 + (size_t)threadIdx.x * 512 + 256 + h * DH;
+                for (int q = 0; q < DH; ++q) l1 += fabsf(wr[q]);
+            }
+            red[threadIdx.x] = l1;
+            __syncthreads();
+            for (int o = 512; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) blk[AttnW::SC + 4 + h] = red[0];
+        }
     }
 }
 

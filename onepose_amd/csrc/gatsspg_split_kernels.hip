@@ -133,6 +133,7 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : 3)) void qkv_kv_sp_kernel
     constexpr int TS = T::BN + 4;
     static_assert(T::BN == QKV_BN && T::WAVES >= 4 && 128 * TS * 4 <= T::RING_BYTES, "one KV partial per 64-column tile");
     float* Tl = smem;
+    float opmx = 0.f;   // largest K (> 0) or |V| entry this wave holds: its 64 rows are all K_h or all V_h
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
@@ -143,8 +144,21 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : 3)) void qkv_kv_sp_kernel
             const float kf = elu1_select(v) + 1.f;
             v = row < 64 ? kf : v;
             v = col >= ts.valid ? 0.f : v;  // pad columns must not enter the sums
+            opmx = fmaxf(opmx, fabsf(v));
             Tl[row * TS + col] = v;
         }
+    if constexpr (T::F16) {
+        // operand maxima for kv_final's bound of the message operator (|KV_h| <= n_src max K max |V|): slots [0..3] max K, [4..7] max |V|,
+        // one per wave; a wave writes its own slot and zeroes its slot of the other kind
+        static_assert(T::WAVES == 4 && T::TM == 2, "waves 0, 1 hold K_h, waves 2, 3 hold V_h");
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) opmx = fmaxf(opmx, __shfl_xor(opmx, o));
+        if (lane == 0) {
+            float* mx = kvpart + ((size_t)ct * H + h) * KVP + DH * DH + DH;
+            mx[wave] = wm == 0 ? opmx : 0.f;
+            mx[4 + wave] = wm == 0 ? 0.f : opmx;
+        }
+    }
     __syncthreads();
     if (wave < 4) {   // (an 8-wave workgroup leaves this short pass to its first four waves)
         const int qi = wave >> 1, di = wave & 1;
@@ -197,7 +211,7 @@ struct AttnFoldSp {
     f32x16 hacc[2][TM];
     float dpart[2];
     const float* ks;   // LDS: ksum of the source segment [4][64]
-    float zfac;        // (scale of the W0 planes) / (scale of the operator planes): exact power of two (1 in the bf16 modes)
+    float zfac[4];     // per head: (scale of the W0 planes) / (scale of the head's operator planes), an exact power of two (1 in the bf16 modes)
     int half;
     template <int I, int TM_>
     __device__ __forceinline__ f32x16 (&target(f32x16 (&acc)[TM_]))[TM_] {
@@ -224,7 +238,7 @@ struct AttnFoldSp {
         float d = dpart[HD & 1];
         const float o = __shfl_xor(d, 32);
         d = half ? o + d : d + o;   // lane half 0's partial first on both halves
-        const float z = zfac / (d + 1e-6f);
+        const float z = zfac[HD] / (d + 1e-6f);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -299,7 +313,11 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::TM == 4 ? 1 : (T::WAVE
     };
     auto bsl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : Qbuf + (size_t)(kt - 8) * BK * ld) + c0; };
     AttnFoldSp<T::TM> hooks;
-    hooks.ks = tab; hooks.zfac = zsc[ts.seg]; hooks.half = half;
+    hooks.ks = tab; hooks.half = half;
+    {
+        const float4 zf = *reinterpret_cast<const float4*>(zsc + ts.seg * H);
+        hooks.zfac[0] = zf.x; hooks.zfac[1] = zf.y; hooks.zfac[2] = zf.z; hooks.zfac[3] = zf.w;
+    }
     SpNoBx nobx;
     auto pre = [&]() {
         if (wave == 0) glds16(ksumT + (size_t)ts.seg * H * DH + 4 * lane, tab);   // [4][64] floats = 1 KiB

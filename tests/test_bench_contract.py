@@ -39,6 +39,10 @@ def test_default_line_contract():
     pc = d["parity_check"]
     assert "reference" in pc["against"] and pc["max_abs_conf_err"] < 1e-4 and pc["argmax_flips"] == 0 and pc["argmax_checked"] == 8000
     assert len(d["config"]["timed_pass_seconds"]) == d["config"]["timed_pass_repetitions"] >= 5
+    # ... and, on trained weights, conf values of O(1) and the thresholded matches (fp32 and fp16x4)
+    for prec, pt in d["parity_check_trained_weights"].items():
+        assert pt["max_abs_conf_err"] < 1e-4 and pt["argmax_flips"] == 0 and pt["matches0_differing_from_reference"] == 0, (prec, pt)
+        assert pt["conf_of_planted_pairs_min_max"][1] > 0.9
 
 
 @gpu
@@ -103,6 +107,27 @@ def test_gpus_n_launches_n_ranks_by_itself():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=120,
                        cwd=ROOT, env=env)
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_configs2_invocation_dry_run():
+    """BASELINE configs[2] ("batch=64 frames sharded 8 per GPU across 8 GPUs") as the driver would launch it, on the CPU stand-in:
+    `python bench.py --gpus 2 --config fp16x4-b8` -> 2 ranks x 8 frames per step; the line names the config and counts frames."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for name in ("fp16x4-b8", "bf16x6-b8"):
+        d = run("--gpus", "2", "--config", name, "--dry-run", "--steps", "6", "--warmup", "1", "--reps", "2", env=env)
+        assert d["n_gpus"] == 2 and d["data"] == "dry-run" and d["config"]["name"] == name and d["config"]["ranks_seen"] == 2
+        assert d["config"]["frames_per_step_per_gpu"] == 8 and d["config"]["frames_per_step_all_gpus"] == 16
+
+
+@gpu
+def test_trained_weights_config_line():
+    """`--config trained`: the headline shape on TRAINED weights; its parity_check compares conf values of O(1) and the thresholded
+    matches with the reference's own output (tests/golden/trained_head.npz)."""
+    d = run("--config", "trained", "--steps", "6", "--warmup", "2", "--reps", "2", "--no-cpu-baseline")
+    pc = d["parity_check"]
+    assert "trained_head" in pc["against"] and pc["max_abs_conf_err"] < 1e-4 and pc["argmax_flips"] == 0
+    assert pc["conf_of_planted_pairs_min_max"][1] > 0.9 and pc["max_abs_conf_err_on_planted_pairs"] < 1e-4
+    assert pc["matches0_differing_from_reference"] == 0 and pc["matches1_differing_from_reference"] == 0 and pc["valid_matches0"] == 500
 
 
 def test_cpu_baseline_legs():
