@@ -205,6 +205,24 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_traffic_source():
+    """Where roofline.traffic comes from, and whether it is of THIS build: the file records the hash of the sources its PMC passes ran on
+    (tools/make_pmc_traffic.py); a different hash is reported as stale instead of being passed off as a measurement of this build."""
+    try:
+        from onepose_amd import build_ext
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            src = json.load(f).get("_source") or {}
+        here = build_ext.source_hash()
+        if not src.get("csrc_sha"):
+            return "profiles/pmc_traffic.json (static; the file does not say which build it was taken on: treat as STALE)"
+        if src["csrc_sha"] == here:
+            return (f"profiles/pmc_traffic.json (static: rocprofv3 PMC passes {src.get('passes')} of THIS build, sources {here}, git {src.get('git_head')}; "
+                    "not measured in this run)")
+        return (f"profiles/pmc_traffic.json -- STALE: its PMC passes ran on sources {src['csrc_sha']} (git {src.get('git_head')}), this run's sources are {here}")
+    except Exception as e:  # noqa: BLE001
+        return f"profiles/pmc_traffic.json (unreadable: {e})"
+
+
 def _timed_cpu(fn, max_seconds):
     """Time fn() on the host: torch's intra-op thread count is chosen among {min(cores, 64), 32, 16} by one trial run each
     (the small per-op GEMMs of these models regress when spread over >100 threads: 256 threads measured 3x slower than 16 on
@@ -986,8 +1004,7 @@ def main():
             "roofline": {"bound": "hbm" if hbm else "mfma", "kernel": args.kernel + "_kernel", "achieved": round(achieved, 2),
                          "peak": peak, "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": pmc_traffic(args.kernel) if args.config == "headline" and not args.shape else None,
-                         "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 PMC passes of this build committed under "
-                                           "profiles/, not measured in this run)" if args.config == "headline" else None,
+                         "traffic_source": pmc_traffic_source() if args.config == "headline" else None,
                          "kernel_ms": round(kern_ms, 5), "empty_event_pair_ms": round(pair_ms, 5),
                          ("algorithmic_bytes_per_launch" if hbm else "flops_per_launch"): fl,
                          "how": f"hipEvent pair on the compute stream around launch #0 of {args.kernel}_kernel in each of {K} "

@@ -52,7 +52,12 @@ typedef struct spp_raw_weights {
  *     SPP_FLAG_PREC_FP16X4 with even H it is RECOMPUTED inside conv1b's fused kernel (conv1ab_pool_f16_kernel) on the f16 MFMA from
  *     fp16-split pixels, weights and bias -- the standalone conv1a kernel is then never launched (spp_forward_profiled with its
  *     kernel id returns an error).  The detector head's softmax, NMS / top-k and the descriptor sampling are fp32 in both modes.
- *     Operand range of the fp16 terms: see include/gatsspg.h (two-term fp16 splits).  Unknown bits are refused. */
+ *     The extractor's fp16 terms are UNSCALED (unlike the matcher's since its ABI 400, include/gatsspg.h): x1 = RNE_fp16(x), x2 =
+ *     RNE_fp16(x - x1), saturating at +-65504; an operand below 2^-3 in magnitude has a subnormal second term, i.e. an absolute error of
+ *     up to 2^-25 per operand instead of the 2^-23 relative one (He-initialised / SuperPoint weights are mostly below 0.06: the products
+ *     then carry ~2^-25 / |w| relative error, 1e-6 at |w| = 0.03).  Measured against the fp32 MFMA on the goldens: score map and
+ *     descriptors within 1e-5 like the fp32 path (tests/test_spp_hip_parity.py); it is a reduced-precision mode with that measured
+ *     tolerance, not a bit-for-bit fp32 replacement.  Unknown bits are refused. */
 #define SPP_FLAG_PREC_FP16X4 0x800
 
 int spp_version(void);

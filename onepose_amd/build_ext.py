@@ -47,6 +47,20 @@ def is_stale():
             or _stale(PNP_LIB_PATH, PNP_SOURCES + PNP_HEADERS))
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the names and contents of every file under csrc/ and include/: identifies the build that a
+    committed measurement (profiles/pmc_traffic.json) was taken on; bench.py says "stale" when it differs from the sources it runs."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (CSRC, os.path.join(HERE, "..", "include")):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".hip", ".h")):
+                h.update(name.encode())
+                with open(os.path.join(d, name), "rb") as f:
+                    h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def tuning_path(lib):
     return lib[:-3] + "_tuning.so"
 

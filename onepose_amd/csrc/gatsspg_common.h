@@ -34,6 +34,7 @@ struct ColLayout {
     // every frame (default: the whole frame).  Lets the per-point kernels run on the query side or the 3D side only.
     int tw_first, tw_count;
     int side_mask;   // bit 0: 2D-side segments active, bit 1: 3D-side segments (segment-level reduction kernels)
+    int xgs;         // XCD granule of a launch's tile map, log2 of column tiles (xcd_tile_map_g; set by the launcher, 0 = one tile)
 };
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -43,7 +44,7 @@ __host__ __device__ inline ColLayout make_layout(int b, int n1, int n2) {
     L.b = b; L.n1 = n1; L.n2 = n2;
     L.n1p = round_up(n1, CP); L.n2p = round_up(n2, CP);
     L.np = L.n1p + L.n2p; L.ld = b * L.np;
-    L.tw_first = 0; L.tw_count = L.np / 64; L.side_mask = 3;
+    L.tw_first = 0; L.tw_count = L.np / 64; L.side_mask = 3; L.xgs = 0;
     return L;
 }
 
@@ -190,7 +191,7 @@ inline Workspace carve_workspace(void* base, int b, int n1, int n2) {
     w.Mpl = (unsigned short*)take(sizeof(unsigned short) * (size_t)w.nseg * 3 * MPL_PLANE);
     w.ksumT = (float*)take(sizeof(float) * (size_t)w.nseg * H * DH);
     w.zsc = (float*)take(sizeof(float) * (size_t)w.nseg * H);
-    w.statpart = (float*)take(sizeof(float) * (size_t)w.nt64 * 2 * 512);
+    w.statpart = (float*)take(sizeof(float) * (size_t)w.nt64 * 2 * 2 * 512);   // one partial per 64 columns, or per 32 (mlp0_sp's transposed epilogue)
     w.stats = (float*)take(sizeof(float) * (size_t)w.nseg * 2 * 512);
     w.statcnt = (int*)take(sizeof(int) * (size_t)w.nseg * 8);
     w.rowpart = (float*)take(sizeof(float) * (size_t)b * w.sc_nct * L.n1p);

@@ -37,7 +37,8 @@ using QkvTileB = GemmTile<128, QKV_BN, 2, 2, false>;      // split-bf16 alternat
 // PREC = 0: exact fp32 MFMA.  PREC = 1: split-bf16 main loop on the pre-split weight planes Whi / Wlo.
 // (forcing 80 VGPRs so that three 8-wave workgroups fit a CU -- the 756 tiles of the headline shape then fit 768 slots in one
 // round -- was measured: kernel -2 %, frames/s in flight unchanged; not kept)
-template <class T, int PREC = 0, int BT = 0>
+// DS: the Q tiles leave straight from the accumulators (store_tile_regs) instead of through an LDS staging tile
+template <class T, int PREC = 0, int BT = 0, int DS = 0>
 __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel(const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
                                                             const unsigned short* __restrict__ Whi,
                                                             const unsigned short* __restrict__ Wlo,
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel
         for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][0][r] = elu1_select(acc[tm][0][r] + bias[tm][r]) + 1.f;
-        store_tile_via_lds<T>(acc, smem, Qbuf + (size_t)rt * 128 * ld + c0, ld, [](int, float v) { return v; });
+        if constexpr (DS) store_tile_regs<T>(acc, Qbuf + (size_t)rt * 128 * ld + c0, ld, [](int, float v) { return v; });
+        else store_tile_via_lds<T>(acc, smem, Qbuf + (size_t)rt * 128 * ld + c0, ld, [](int, float v) { return v; });
         return;
     }
     // ---- K_h / V_h tile -> LDS -> KV partial ----
@@ -542,17 +544,22 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(c
 //     out).  The cancellation-prone part is evaluated in double precision, where it is harmless, and the fp32 rounding
 //     of sum_t enters only at second order (d M2 / d sum_t = 2 (mean_t - mean)).  Fixed order: 64 channels x 16
 //     tile-ranges per block, ranges summed in tile order and combined in range order.
+// TW: columns per partial -- MLP0_BN (64) from the channel-major mlp.0 kernels, 32 from mlp0_sp's transposed epilogue (one per wave strip).
+// A block = ROWS channels x PARTS tile ranges; with twice the partials (TW = 32) it takes half the channels and twice the ranges, so that a
+// range is still one batch of <= 8 loads at the headline shape (the first form kept 64 x 16 and paid a second dependent round trip: +1 us).
+template <int TW>
 __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restrict__ statpart, float* __restrict__ stats,
                                                           ColLayout L) {
-    __shared__ double red[2][16][64];
-    const int rl = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int seg = blockIdx.x, row = blockIdx.y * 64 + rl;
+    constexpr int ROWS = TW == 32 ? 32 : 64, PARTS = 1024 / ROWS;
+    __shared__ double red[2][PARTS][ROWS];
+    const int rl = threadIdx.x % ROWS, part = threadIdx.x / ROWS;
+    const int seg = blockIdx.x, row = blockIdx.y * ROWS + rl;
     const int frame = seg >> 1, side = seg & 1;
     if (!((L.side_mask >> side) & 1)) return;
-    const int t0 = (frame * L.np + (side ? L.n1p : 0)) / MLP0_BN;
-    const int nt = (side ? L.n2p : L.n1p) / MLP0_BN;
+    const int t0 = (frame * L.np + (side ? L.n1p : 0)) / TW;
+    const int nt = (side ? L.n2p : L.n1p) / TW;
     const int n = side ? L.n2 : L.n1;
-    const int per = (nt + 15) / 16;
+    const int per = (nt + PARTS - 1) / PARTS;
     const int tb = part * per, te = min(nt, tb + per);
     double S = 0.0, QP = 0.0;
     for (int tt = tb; tt < te; tt += 8) {   // 2 x 8 loads in flight at a time on clamped addresses (see kv_final_kernel)
@@ -566,10 +573,10 @@ __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restric
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int t = tt + u;
-            const int nv = min(MLP0_BN, n - t * MLP0_BN);   // real columns of tile t of this segment (<= 0: pad-only tile)
+            const int nv = min(TW, n - t * TW);   // real columns of tile t of this segment (<= 0: pad-only tile)
             if (t < te && nv > 0) {
                 const double st = (double)xs[u], mt = (double)xm[u];
-                const double inv = nv == MLP0_BN ? 1.0 / MLP0_BN : 1.0 / nv;
+                const double inv = nv == TW ? 1.0 / TW : 1.0 / nv;
                 S += st;
                 QP += mt + st * st * inv;
             }
@@ -582,7 +589,7 @@ __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restric
         S = red[0][0][rl];
         QP = red[1][0][rl];
 #pragma unroll
-        for (int p = 1; p < 16; ++p) {
+        for (int p = 1; p < PARTS; ++p) {
             S += red[0][p][rl];
             QP += red[1][p][rl];
         }
@@ -602,7 +609,8 @@ using Mlp3TileTallW8 = GemmTile<128, 64, 4, 2, false>;   // both arithmetics: 12
 using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;          // alternative (tuning builds): 64x64 on 4 waves, 504 workgroups
 using Mlp3TileS = GemmTile<64, 64, 2, 2, false, false, 2>;   // fp32, launches that leave CUs empty: 64x64, two K groups of 4 waves
 
-template <class T, int ABL = 0, int PREC = 0>
+// DS: the output tile leaves straight from the accumulators (store_tile_regs; plain 128 x 64 / 64 x 64 tiles, not the K-split one)
+template <class T, int ABL = 0, int PREC = 0, int DS = 0>
 __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
                                                    const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
                                                    const unsigned short* __restrict__ Wl2,
@@ -665,7 +673,8 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp3_kernel(c
             acc, smem, 512 / BK, al, 512, bl, ld, xm, xr, bx);
     }
     ksplit_reduce<T>(acc, smem);
-    store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [](int, float v) { return v; });
+    if constexpr (DS && T::KS == 1) store_tile_regs<T>(acc, Z + (size_t)rt * T::BM * ld + c0, ld, [](int, float v) { return v; });
+    else store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [](int, float v) { return v; });
 }
 
 // =====================================================================================================
@@ -993,12 +1002,17 @@ void allow_big_lds() {
     }
 }
 
-template <class T, int PREC, int BT = 0>
+// fp32 kernels (8-wave tiles): output tiles straight from the accumulators.  bit 0: the Q tiles of qkv_kv, bit 1: mlp3.  Tuning builds read
+// GATSSPG_FP32_DIRECT per launch (tools/ab_live.py); the product takes the default.
+constexpr int FP32_DIRECT_DEFAULT = 3;
+static int fp32_direct() { return tuning_knob("FP32_DIRECT", FP32_DIRECT_DEFAULT); }
+
+template <class T, int PREC, int BT = 0, int DS = 0>
 static void launch_qkv_t(const float* Wqkv, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s,
                          ProfileHook* hk) {
     const int NT = active_tiles(w.L);
-    allow_big_lds<qkv_kv_kernel<T, PREC, BT>>();
-    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_kernel<T, PREC, BT>), dim3(xcd_grid(6, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>() + 512 * BT), s,
+    allow_big_lds<qkv_kv_kernel<T, PREC, BT, DS>>();
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_kernel<T, PREC, BT, DS>), dim3(xcd_grid(6, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>() + 512 * BT), s,
                    Wqkv, bqkv, wb ? wb + (PREC >= 3 ? AttnWB::QKV_H16 : AttnWB::QKV_HI) : nullptr,
                    wb ? wb + (PREC >= 3 ? AttnWB::QKV_L16 : AttnWB::QKV_LO) : nullptr, wb ? wb + AttnWB::QKV_LO2 : nullptr, w.Z,
                    w.Q, w.kvpart, w.L);
@@ -1047,7 +1061,10 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* w
 #ifdef GATSSPG_TUNING
     else if (fp32_bias_table()) launch_qkv_t<QkvTileW8, 0, 1>(Wqkv, bqkv, wb, w, s, hk);
 #endif
-    else launch_qkv_t<QkvTileW8, 0>(Wqkv, bqkv, wb, w, s, hk);
+#ifdef GATSSPG_TUNING
+    else if (!(fp32_direct() & 1)) launch_qkv_t<QkvTileW8, 0>(Wqkv, bqkv, wb, w, s, hk);
+#endif
+    else launch_qkv_t<QkvTileW8, 0, 0, (FP32_DIRECT_DEFAULT & 1)>(Wqkv, bqkv, wb, w, s, hk);
 }
 
 void launch_kv_final(const float* W0, const Workspace& w, int cross, const float* kv_src, hipStream_t s, ProfileHook* hk) {
@@ -1074,12 +1091,12 @@ static void launch_mlp0_t(const float* W0, const float* b0, const unsigned short
                    wb ? wb + AttnWB::W0_LO2 : nullptr, w.Z, w.Q, w.Mop, w.Mpl, w.ksumT, w.U,
                    w.statpart, w.stats, stat_fused() ? w.statcnt : nullptr, w.L, g_trace);
 }
-template <class T, int ABL, int PREC>
+template <class T, int ABL, int PREC, int DS = 0>
 static void launch_mlp3_t(const float* W3, const float* b3, const unsigned short* wb, const Workspace& w, hipStream_t s,
                           ProfileHook* hk) {
-    allow_big_lds<mlp3_kernel<T, ABL, PREC>>();
+    allow_big_lds<mlp3_kernel<T, ABL, PREC, DS>>();
     const int NT = active_tiles(w.L) / (T::BN / 64);
-    GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_kernel<T, ABL, PREC>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS),
+    GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_kernel<T, ABL, PREC, DS>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS),
                    (smem_bytes<T, PREC>()), s, W3, b3, wb ? wb + (PREC >= 3 ? AttnWB::W3_H16 : AttnWB::W3_HI) : nullptr,
                    wb ? wb + (PREC >= 3 ? AttnWB::W3_L16 : AttnWB::W3_LO) : nullptr, wb ? wb + AttnWB::W3_LO2 : nullptr, w.U,
                    w.stats, w.Z, w.L);
@@ -1114,9 +1131,11 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else if (fp32_bias_table()) launch_mlp0_t<Mlp0TileW8, 0, 0, 1>(W0, b0, wb, w, s, hk);
 #endif
     else launch_mlp0_t<Mlp0TileW8, 0, 0>(W0, b0, wb, w, s, hk);
-    // (the InstanceNorm statistics are finished inside the mlp.0 launch by its last workgroups: stat_last_block; tuning builds keep the
-    //  separate reducer launch for A/B runs, GATSSPG_STAT_FUSED=0)
-    if (!stat_fused()) GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
+    // the InstanceNorm reducer is a launch of its own (stat_final_kernel: measured faster one frame at a time than finishing the statistics
+    // inside the mlp.0 launch by its last workgroups -- stat_last_block; that form is GATSSPG_STAT_FUSED=1 in tuning builds)
+    if (sp && !(dma & 2) && sp_ut_on(w.prec))
+        GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel<32>, dim3(w.nseg, 16), dim3(1024), 0, s, w.statpart, w.stats, w.L);
+    else if (!stat_fused()) GATSSPG_LAUNCH(hk, KID_STAT_FINAL, s, stat_final_kernel<MLP0_BN>, dim3(w.nseg, 8), dim3(1024), 0, s, w.statpart, w.stats, w.L);
     if (dma & 4) launch_mlp3_dma(W3, b3, w, s, hk);
     else if (sp) launch_mlp3_sp(sc, b3, wb, w, s, hk);
     else if (small3 && t3 == 1) launch_mlp3_t<Mlp3TileS, 0, 0>(W3, b3, wb, w, s, hk);
@@ -1126,7 +1145,10 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
 #ifdef GATSSPG_PROFILING_BUILD
     else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3, 0>(W3, b3, wb, w, s, hk);   // steady-state loop cut: fixed cost only
 #endif
-    else if (t3 == 1) launch_mlp3_t<Mlp3TileTallW8, 0, 0>(W3, b3, wb, w, s, hk);
+#ifdef GATSSPG_TUNING
+    else if (t3 == 1 && !(fp32_direct() & 2)) launch_mlp3_t<Mlp3TileTallW8, 0, 0>(W3, b3, wb, w, s, hk);
+#endif
+    else if (t3 == 1) launch_mlp3_t<Mlp3TileTallW8, 0, 0, ((FP32_DIRECT_DEFAULT >> 1) & 1)>(W3, b3, wb, w, s, hk);
     else launch_mlp3_t<Mlp3Tile, 0, 0>(W3, b3, wb, w, s, hk);
 }
 

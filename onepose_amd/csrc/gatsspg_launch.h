@@ -66,8 +66,12 @@ void launch_mlp0_dma(const float* W0, const float* b0, const Workspace& w, hipSt
 void launch_mlp3_dma(const float* W3, const float* b3, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 // true if the split-precision launch goes to the kernels above (fp16 modes: always; bf16 modes: unless a tuning build says otherwise)
 bool split_loop_glds(int prec);
-// true: the InstanceNorm statistics are finished inside the mlp.0 launch (no stat_final launch); false only in tuning builds
+// true (tuning builds, GATSSPG_STAT_FUSED=1): the InstanceNorm statistics are finished inside the mlp.0 launch by its last workgroups
+// (stat_last_block); the product path is the separate stat_final launch (measured faster one frame at a time: DESIGN.md 14e)
 bool stat_fused();
+// true: mlp.0 of the split loop writes U point-major (U^T [ld][512]) with InstanceNorm partials per 32-point strip and mlp.3 reads it as
+// a transposed B operand (fp16 modes; gatsspg_split_kernels.hip).  stat_final then merges 32-column partials.
+bool sp_ut_on(int prec);
 void launch_final_proj_norm(const float* Wf, const float* bf, const Workspace& w, hipStream_t s, ProfileHook* hk = nullptr);
 // shifted = 0: E = exp(S) into conf + row/col sum partials (|S| <= 80); 1: raw scores S into conf (max-subtracting path)
 void launch_score_exp(const Workspace& w, float* conf, float scale, int shifted, hipStream_t s, ProfileHook* hk = nullptr);

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : 3)) void qkv_kv_sp_kernel
     float* smem = reinterpret_cast<float*>(smem_c);
     if constexpr (T::F16) fp16_saturate_mode();
     int rt, ct;
-    if (!xcd_tile_map(6, active_tiles(L), rt, ct)) return;
+    if (!xcd_tile_map_g(6, active_tiles(L), L.xgs, rt, ct)) return;
     ct = global_tile(L, ct);
     const int c0 = ct * T::BN, ld = L.ld;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -204,7 +204,10 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : 3)) void qkv_kv_sp_kernel
 //     added over the head's four halves in a fixed order, the two lane halves combined by one exchange -- per-lane in exactly the
 //     32x32 C layout the fold needs, no LDS round trip.
 // =====================================================================================================
-template <int TM>
+// UT (transposed accumulators, SP_OPT_SWAP of the main loop: lane = channel, register r = point mfma_row(r, half) of the wave's 32-point
+// strip): the denominator of point p is still summed by lane l31 = p (the raw B values a lane holds are those of ITS point), so a fold
+// takes the factors of its registers' points from one rank-1 fp32 MFMA (z x 1: the accumulator layout of the tile itself).
+template <int TM, bool UT = false>
 struct AttnFoldSp {
     static constexpr bool ENABLED = true;
     static constexpr int SPLIT = 8;
@@ -239,10 +242,25 @@ struct AttnFoldSp {
         const float o = __shfl_xor(d, 32);
         d = half ? o + d : d + o;   // lane half 0's partial first on both halves
         const float z = zfac[HD] / (d + 1e-6f);
+        if constexpr (!UT) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) kept[tm][r] = fmaf(z, hacc[HD & 1][tm][r], kept[tm][r]);
+                for (int r = 0; r < 16; ++r) kept[tm][r] = fmaf(z, hacc[HD & 1][tm][r], kept[tm][r]);
+        } else {
+            // register r of a lane holds point mfma_row(r, half) of the strip; the factor of point p sits in lane p.  ONE fp32 MFMA hands
+            // every lane the 16 factors of its registers' points: D[i][j] = sum_k A[i][k] B[k][j] with A[i][0] = z_i, B[0][j] = 1 (k = 1
+            // operands zero) = z_i for every column j, in the accumulator layout of the tile itself (exact: z * 1 + 0 * 0).  64 cycles of
+            // matrix pipe per head and wave instead of 2 v_readlane + 2 v_mov + 1 v_cndmask per register (measured: +1.4 % per frame).
+            f32x16 zm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zm[r] = 0.f;
+            zm = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? 0.f : z, half ? 0.f : 1.f, zm, 0, 0, 0);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) kept[tm][r] = fmaf(zm[r], hacc[HD & 1][tm][r], kept[tm][r]);
+        }
     }
     // head h - 1 is folded beside the first products of head h (its own products were issued a whole slab earlier)
     template <int I, int TM_>
@@ -312,7 +330,11 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::TM == 4 ? 1 : (T::WAVE
         }
     };
     auto bsl = [&](int kt) { return (kt < 8 ? Z + (size_t)kt * BK * ld : Qbuf + (size_t)(kt - 8) * BK * ld) + c0; };
-    AttnFoldSp<T::TM> hooks;
+    // EPI bit 3 (UT): transposed accumulators -- U leaves POINT-major (U^T [ld][512]: mlp3_sp reads 8 consecutive channels of a point
+    // with two 16-byte LDS reads) straight from the registers, and the InstanceNorm partials are summed inside a lane (one per 32-point
+    // strip of a wave): no staging tile, no barrier, no statistics walk behind the loop (round-4 trace: 9 k of a wave's 39.5 k cycles)
+    constexpr bool UT = (EPI & 8) != 0;
+    AttnFoldSp<T::TM, UT> hooks;
     hooks.ks = tab; hooks.half = half;
     {
         const float4 zf = *reinterpret_cast<const float4*>(zsc + ts.seg * H);
@@ -325,15 +347,71 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::TM == 4 ? 1 : (T::WAVE
             if (wave == 1 && lane < 32) glds16(b0 + rt * T::BM + 4 * lane, btab);   // 128 floats: half a piece
         }
     };
-    gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), AttnFoldSp<T::TM>, SpNoBx, ABL, SCHED, decltype(pre)>(
+    gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), AttnFoldSp<T::TM, UT>, SpNoBx, ABL, SCHED, decltype(pre), (UT ? SP_OPT_SWAP : 0)>(
         reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, nobx, &tr, pre, SP_TRACE_ON(trace), T::F32 ? 512 * 4 : 64);
     if (SP_TRACE_ON(trace)) tr.t[9] = __builtin_readcyclecounter();    // behind the loop's last barrier
     hooks.template fold<3>(reinterpret_cast<f32x16(&)[T::TM]>(acc));
-    if constexpr (BIAS_TAB) read_bias16<T>(btab, wm, half, bias);
     if constexpr (ABL & 32) {   // timing only: no epilogue at all (one store keeps the accumulators alive)
         if (acc[0][0][0] == 123.456f) U[0] = acc[T::TM - 1][0][5];
         return;
     }
+    if constexpr (UT) {
+        static_assert(BIAS_TAB, "the transposed epilogue reads its bias (one value per lane and 32-channel block) from the LDS table");
+        // lane = channel ch[tm] of the workgroup's 128, register r = point pt0 + mfma_row(r, half) of this wave's 32-point strip
+        const int pt0 = wn * 32;
+        const int vw = min(max(ts.valid - pt0, 0), 32);   // real points of the strip
+        float* Ut = U + (size_t)(c0 + pt0) * 512 + rt * T::BM;
+        const size_t t32 = (size_t)(c0 + pt0) / 32;
+#pragma unroll
+        for (int tm = 0; tm < T::TM; ++tm) {
+            const int ch = (wm * T::TM + tm) * 32 + l31;
+            const float bch = btab[ch];
+            float u[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = fmaf(acc[tm][0][r], inv, bch);
+            // a store instruction = two points x 32 consecutive channels = two full 128-byte lines of U^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (ABL & 16) { if (u[r] == 123.456f) U[0] = u[r]; }
+                else Ut[(size_t)mfma_row(r, half) * 512 + ch] = u[r];
+            }
+            // (sum, pivot-shifted centred sum of squares) of the strip's real points: mlp0_kernel's partial on a 32-point tile, summed in
+            // the lane, the two lane halves combined by one exchange (half 0 first on both)
+            const float pivot = __shfl(u[0], l31);   // point pt0 (register 0 of lane half 0)
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = mfma_row(r, half) < vw ? u[r] - pivot : 0.f;
+                s1 += d;
+                s2 = fmaf(d, d, s2);
+            }
+            const float o1 = __shfl_xor(s1, 32), o2 = __shfl_xor(s2, 32);
+            s1 = half ? o1 + s1 : s1 + o1;
+            s2 = half ? o2 + s2 : s2 + o2;
+            if (half == 0) {
+                const float nv = (float)vw;
+                statpart[(t32 * 2 + 0) * 512 + rt * T::BM + ch] = nv * pivot + s1;
+                statpart[(t32 * 2 + 1) * 512 + rt * T::BM + ch] = nv > 0.f ? s2 - s1 * s1 / nv : 0.f;
+            }
+        }
+        if (SP_TRACE_ON(trace)) { tr.t[10] = tr.t[11] = tr.t[12] = __builtin_readcyclecounter(); }
+        (void)statcnt; (void)stats;
+        if (SP_TRACE_ON(trace) && lane == 0) {
+            unsigned long long* rr = trace + ((size_t)blockIdx.x * T::WAVES + wave) * 24;
+            rr[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            rr[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            rr[2] = t_entry;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) rr[3 + k] = tr.t[k];
+            rr[12] = __builtin_readcyclecounter();
+            rr[13] = rt; rr[14] = ct; rr[15] = wave;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rr[16 + k] = tr.t[9 + k];
+            rr[20] = w_entry; rr[21] = wall_clock64();
+        }
+        return;
+    }
+    if constexpr (BIAS_TAB) read_bias16<T>(btab, wm, half, bias);
 
     // staging tile [BM][BN + 4]: the row stride (4 banks) keeps the scalar writes from the MFMA layout, the 16-byte row reads of the
     // store pass AND (with the walk skew below) the statistics reads free of bank conflicts (the [BN + 1] form of the fp32 kernel costs
@@ -464,7 +542,7 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::NST == 2 ? 3 : 2)) voi
     int rt, ct;
     constexpr int MT = 256 / T::BM;
     constexpr int TPW = T::BN / 64;
-    if (!xcd_tile_map(MT, active_tiles(L) / TPW, rt, ct)) return;
+    if (!xcd_tile_map_g(MT, active_tiles(L) / TPW, L.xgs, rt, ct)) return;
     ct = global_tile(L, ct * TPW) / TPW;
     const int c0 = ct * T::BN, ld = L.ld;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -493,15 +571,17 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : T::NST == 2 ? 3 : 2)) voi
         if constexpr (T::F32) return reinterpret_cast<const float*>(P0) + (size_t)rt * T::BM * 512 + kt * BK;   // fp32 W3 [256][512]
         else return (pl == 0 ? P0 : pl == 1 ? P1 : P2) + ro + (size_t)kt * 256 * BK;
     };
-    auto bsl = [&](int kt) { return U + (size_t)kt * BK * ld + c0; };
+    // EPI bit 3 (BT): U arrives point-major (U^T [ld][512], written by mlp0_sp's transposed epilogue): SP_OPT_BT of the main loop
+    constexpr bool BT = (EPI & 8) != 0;
+    auto bsl = [&](int kt) { return BT ? U + (size_t)c0 * 512 + kt * BK : U + (size_t)kt * BK * ld + c0; };
     SpPlainHooks<false> hooks;
     InstNormBx bx;
     bx.tab = tab;
     auto pre = [&]() {
         if (wave < 4) glds16(stats + (size_t)ts.seg * 2 * 512 + wave * 256 + 4 * lane, tab + wave * 256);
     };
-    gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), SpPlainHooks<false>, InstNormBx, 0, SCHED, decltype(pre)>(
-        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, ld, hooks, bx, nullptr, pre, false, T::F32 ? 512 * 4 : 64);
+    gemm_mainloop_sp<T, 512 / BK, decltype(apl), decltype(bsl), SpPlainHooks<false>, InstNormBx, 0, SCHED, decltype(pre), (BT ? SP_OPT_BT : 0)>(
+        reinterpret_cast<f32x16(&)[T::TM]>(acc), smem_c, apl, bsl, BT ? 512 : ld, hooks, bx, nullptr, pre, false, T::F32 ? 512 * 4 : 64);
     if constexpr (EPI & 1) store_tile_direct<T>(acc, Z + (size_t)rt * T::BM * ld + c0, ld, [inv](int, float v) { return v * inv; });
     else store_tile_via_lds<T>(acc, smem, Z + (size_t)rt * T::BM * ld + c0, ld, [inv](int, float v) { return v * inv; });
 }
@@ -642,12 +722,42 @@ static int sp_sched() { return tuning_knob("SP_SCHED", SP_SCHED_DEFAULT); }
 // 1: qkv_kv / mlp0 read their bias from an LDS table filled by one LDS-DMA piece (no global loads in front of the first slab requests); 0: per-lane
 // 16-byte global loads before the loop (schedule 4 only; the other schedules keep the loads)
 static int sp_bias_table() { return tuning_knob("SP_BIAS_TABLE", 1); }
+// fp16 modes, TUNING BUILDS ONLY (GATSSPG_SP_UT=1): mlp.0 leaves U point-major from TRANSPOSED accumulators (swapped MFMA operands: no staging tile,
+// no barrier, InstanceNorm partials summed inside a lane per 32-point strip) and mlp.3 reads it as a transposed B operand (two 16-byte LDS reads
+// per k16 half instead of eight 4-byte ones).  Built, parity-green (zero arg-max flips, the same conf error) and measured in round 5
+// (profiles/r05c_ab_live_ut_xcd_direct.txt, settings interleaved in one process): mlp0 23.5 vs 23.8 us event-timed, mlp3 16.7 vs 16.9 -- but
+// 0.693 vs 0.688 ms per frame and 1908 vs 1925 frames/s in flight: the transposed fold needs the per-point factor in 16 registers (one rank-1
+// fp32 MFMA per head), the kernel holds 237-243 registers instead of 192 (no other frame's wave fits beside it) and stat_final merges twice the
+// partials.  The product library runs the channel-major pair; the alternative schedules / tiles / ablations exist in that form only.
+bool sp_ut_on(int prec) {
+    if constexpr (!TUNING_BUILD) return false;
+    if (prec < 3) return false;
+    const int nst2 = tuning_knob("SP_NST2", -1);
+    if (sp_sched() != 4 || !sp_bias_table() || (sp_direct_store() & 2) == 0 || tuning_knob("SP_ABL", 0) != 0 || (nst2 > 0 && (nst2 & 1)) || stat_fused())
+        return false;
+    return tuning_knob("SP_UT", 0) != 0;
+}
+
+// mlp0's tile choice (launch_mlp0_sp_m) and, from it, the XCD granule of the 64-column kernels beside it: with the 128-column mlp0 tile an XCD
+// can own PAIRS of 64-column tiles in qkv_kv / mlp3 as well, so that a column range stays on the XCD (= the L2) that produced it across
+// mlp3 -> qkv_kv -> mlp0 -> mlp3.  Measured (profiles/r05c_ab_live_ut_xcd_direct.txt, interleaved in one process): no effect (0.6927 vs 0.6928 ms per
+// frame, 1912 vs 1908 frames/s in flight) -- the operands of these launches are not waiting for a remote L2.  Off; GATSSPG_SP_XCD_PAIR=1 in tuning builds.
+static bool mlp0_sp_wide(const ColLayout& L) {
+    const int wide_min = tuning_knob("SP_MLP0_WIDE_MIN", 48), wide_max = tuning_knob("SP_MLP0_WIDE_MAX", 64);
+    return active_tiles(L) / 2 >= wide_min && active_tiles(L) / 2 <= wide_max;
+}
+static ColLayout sp_paired_layout(const ColLayout& L0, int prec) {
+    ColLayout L = L0;
+    L.xgs = (prec >= 3 && mlp0_sp_wide(L0) && tuning_knob("SP_XCD_PAIR", 0) != 0) ? 1 : 0;
+    return L;
+}
 
 template <class T, int SCHED, int EPI>
 static void launch_qkv_sp_v(const float* sc, const float* bqkv, const PlaneSet& p, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     allow_big_lds_sp<qkv_kv_sp_kernel<T, SCHED, EPI>>();
-    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, SCHED, EPI>), dim3(xcd_grid(6, active_tiles(w.L))), dim3(T::THREADS), (size_t)T::RING_BYTES + 1024, s,
-                   sc, bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, w.L);
+    const ColLayout L = sp_paired_layout(w.L, T::MODE);
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_sp_kernel<T, SCHED, EPI>), dim3(xcd_grid_g(6, active_tiles(L), L.xgs)), dim3(T::THREADS), (size_t)T::RING_BYTES + 1024, s,
+                   sc, bqkv, p.p0, p.p1, p.p2, w.Z, w.Q, w.kvpart, L);
 }
 template <int MODE>
 static void launch_qkv_sp_t(const float* sc, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s, ProfileHook* hk) {
@@ -729,8 +839,7 @@ static void launch_mlp0_sp_m(const float* sc, const float* b0, const unsigned sh
     // its 4 x tiles workgroups make ONE round of the 256 CUs and fill at least three quarters of it (the headline shape: 252); with
     // fewer the 64-column tile (4 waves, two workgroups per CU, twice as many) fills the chip better, with more than one round its
     // co-resident pairs overlap one workgroup's store tail with the other's loop (fp16x4, 8 frames per step: 173 vs 185 us per launch)
-    const int wide_min = tuning_knob("SP_MLP0_WIDE_MIN", 48), wide_max = tuning_knob("SP_MLP0_WIDE_MAX", 64);
-    const bool wide = active_tiles(w.L) / 2 >= wide_min && active_tiles(w.L) / 2 <= wide_max;
+    const bool wide = mlp0_sp_wide(w.L);
     if constexpr (TUNING_BUILD) {
         if constexpr (MODE == 4) {   // timing-only ablations of the main loop (wrong results) and the alternative tiles
             switch (tuning_knob("SP_ABL", 0)) {
@@ -772,6 +881,13 @@ static void launch_mlp0_sp_m(const float* sc, const float* b0, const unsigned sh
         }
     }
     if constexpr (MODE >= 3) {
+        if constexpr (TUNING_BUILD) {
+            if (sp_ut_on(MODE)) {   // EPI 2 | 8: bias through its LDS table, transposed accumulators -> U^T + in-lane statistics
+                if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, SP_SCHED_DEFAULT, 10>(sc, b0, wb, w, s, hk);
+                else launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, SP_SCHED_DEFAULT, 10>(sc, b0, wb, w, s, hk);
+                return;
+            }
+        }
         if (wide) launch_mlp0_sp_t<Mlp0SpTileW<MODE>, 0, SP_SCHED_DEFAULT, 2>(sc, b0, wb, w, s, hk);   // (EPI 2: bias through its LDS table)
         else launch_mlp0_sp_t<Mlp0SpTileN<MODE>, 0, SP_SCHED_DEFAULT, 2>(sc, b0, wb, w, s, hk);
     } else {   // bf16 modes (tuning builds)
@@ -793,8 +909,9 @@ void launch_mlp0_sp(const float* sc, const float* b0, const unsigned short* wb, 
 template <class T, int SCHED, int EPI>
 static void launch_mlp3_sp_v(const float* sc, const float* b3, const PlaneSet& p, int NT, const Workspace& w, hipStream_t s, ProfileHook* hk) {
     allow_big_lds_sp<mlp3_sp_kernel<T, SCHED, EPI>>();
-    GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, SCHED, EPI>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc, b3,
-                   p.p0, p.p1, p.p2, w.U, w.stats, w.Z, w.L);
+    const ColLayout L = sp_paired_layout(w.L, T::MODE);
+    GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_sp_kernel<T, SCHED, EPI>), dim3(xcd_grid_g(256 / T::BM, NT, L.xgs)), dim3(T::THREADS), (size_t)T::RING_BYTES + 4096, s, sc, b3,
+                   p.p0, p.p1, p.p2, w.U, w.stats, w.Z, L);
 }
 // the schedule / store variants of one mlp3 tile (tuning builds); false = take the default
 template <class T>
@@ -820,6 +937,13 @@ static void launch_mlp3_sp_t(const float* sc, const float* b3, const unsigned sh
         const bool two_stage = nst2 >= 0 ? (nst2 & 2) != 0 : (256 / T2::BM) * NT > 512;
         if constexpr (TUNING_BUILD) {
             if (two_stage ? launch_mlp3_sp_alt<T2>(sc, b3, p, NT, w, s, hk) : launch_mlp3_sp_alt<T>(sc, b3, p, NT, w, s, hk)) return;
+        }
+        if constexpr (TUNING_BUILD) {
+            if (sp_ut_on(MODE)) {   // EPI 1 | 8: direct stores, U read point-major
+                if (two_stage) launch_mlp3_sp_v<T2, SP_SCHED_DEFAULT, 9>(sc, b3, p, NT, w, s, hk);
+                else launch_mlp3_sp_v<T, SP_SCHED_DEFAULT, 9>(sc, b3, p, NT, w, s, hk);
+                return;
+            }
         }
         if (two_stage) launch_mlp3_sp_v<T2, SP_SCHED_DEFAULT, 1>(sc, b3, p, NT, w, s, hk);
         else launch_mlp3_sp_v<T, SP_SCHED_DEFAULT, 1>(sc, b3, p, NT, w, s, hk);

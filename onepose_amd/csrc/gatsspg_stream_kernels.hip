@@ -238,35 +238,30 @@ __global__ __launch_bounds__(256, 7) void gats_leaf8x4_kernel(const float* __res
         if (lane < 32) redl[w][leaf_logit_slot(lane)] = s;
     }
     __syncthreads();
-    if (tid < 4) {
+    if (tid < 64) {
+        // softmax over the 1 + 8 logits of each of the 4 points on 4 x 16 lanes of wave 0: lane = point * 16 + j, j = 0 the point itself,
+        // 1..8 its leaves (round 4 ran it on 4 threads with 9 logits each: ~250 serial instructions on every workgroup's critical path and a
+        // 12-byte scratch spill under the kernel's 72-register budget).  Same values: max is order-free, and every lane adds the nine
+        // exponentials in the order 0, 1, ..., 8 that the four-thread form used (excluded entries contribute an exact 0).
         const int include_self = flags & GATSSPG_FLAG_INCLUDE_SELF;
-        const float s3 = (red3[0][tid] + red3[1][tid]) + (red3[2][tid] + red3[3][tid]);
-        float e[9];
-        e[0] = lrelu02(s3 + s3);
+        const int p4 = lane >> 4, j = lane & 15;
+        const bool in = j < 9 && (j > 0 || include_self);
+        const float s3 = (red3[0][p4] + red3[1][p4]) + (red3[2][p4] + red3[3][p4]);
+        const int c = p4 * 8 + min(max(j - 1, 0), 7);
+        const float ll = CACHED_LOGITS ? redl[0][c] : (redl[0][c] + redl[1][c]) + (redl[2][c] + redl[3][c]);
+        const float e = lrelu02(s3 + (j == 0 ? s3 : ll));
+        float m = in ? e : -3.0e38f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = tid * 8 + j;
-            e[1 + j] = lrelu02(s3 + (CACHED_LOGITS ? redl[0][c] : (redl[0][c] + redl[1][c]) + (redl[2][c] + redl[3][c])));
-        }
-        float m = include_self ? e[0] : e[1];
-#pragma unroll
-        for (int j = 1; j < 9; ++j) m = fmaxf(m, e[j]);
+        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const float ex = in ? expf(e - m) : 0.f;
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            if (j > 0 || include_self) {
-                e[j] = expf(e[j] - m);
-                sum += e[j];
-            }
-        }
-        if (include_self) {
-            coef[tid][0] = e[0] / sum + ((flags & GATSSPG_FLAG_ADDITIONAL) && !raw_out ? 1.f : 0.f);
-#pragma unroll
-            for (int j = 1; j < 9; ++j) coef[tid][j] = e[j] / sum;
-        } else {
-            coef[tid][0] = 1.f;
-#pragma unroll
-            for (int j = 1; j < 9; ++j) coef[tid][j] = (e[j] / sum) / 2.f;
+        for (int k = 0; k < 9; ++k) sum += __shfl(ex, (lane & 48) + k);
+        if (j < 9) {
+            float cf;
+            if (include_self) cf = ex / sum + (j == 0 && (flags & GATSSPG_FLAG_ADDITIONAL) && !raw_out ? 1.f : 0.f);
+            else cf = j == 0 ? 1.f : (ex / sum) / 2.f;
+            coef[p4][j] = cf;
         }
     }
     __syncthreads();

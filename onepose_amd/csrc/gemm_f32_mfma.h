@@ -899,6 +899,26 @@ __device__ __forceinline__ void store_tile_via_lds(const f32x16 (&acc)[T::TM][T:
     }
 }
 
+// A plain output tile straight from the accumulators: in the 32 x 32 C layout a lane's 16 values of one product sit in ONE column (lane & 31)
+// and 16 rows, so each dword store instruction covers two rows x 32 consecutive columns = two full 128-byte lines -- no LDS round trip and
+// no barrier in front of the stores (store_tile_via_lds: 16 scalar LDS writes per 32 x 32 block, a barrier, row reads, 16-byte stores).
+template <class T, class F>
+__device__ __forceinline__ void store_tile_regs(const f32x16 (&acc)[T::TM][T::TN], float* dst, int ld, F f) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % T::WAVES_MN;
+    const int wm = wave / T::WN, wn = wave % T::WN, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn) {
+            float* d = dst + (wn * T::TN + tn) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * T::TM + tm) * 32 + mfma_row(r, half);
+                d[(size_t)row * ld] = f(row, acc[tm][tn][r]);
+            }
+        }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
 #pragma unroll
@@ -1001,6 +1021,17 @@ __device__ __forceinline__ bool xcd_tile_map(int MT, int NT, int& rt, int& ct) {
     return ct < NT;
 }
 inline int xcd_grid(int MT, int NT) { return 8 * MT * ((NT + 7) / 8); }
+// The same with an XCD owning GROUPS of 2^gs consecutive column tiles: kernels whose column tiles are half as wide as a neighbour kernel's
+// (qkv_kv / mlp3 on 64 columns beside mlp0_sp on 128) then keep a column range on the XCD whose L2 its producer wrote it into.
+__device__ __forceinline__ bool xcd_tile_map_g(int MT, int NT, int gs, int& rt, int& ct) {
+    const int g = blockIdx.x;
+    const int xcd = g & 7, slot = g >> 3;
+    rt = slot % MT;
+    const int cs = slot / MT;
+    ct = ((((cs >> gs) << 3) + xcd) << gs) + (cs & ((1 << gs) - 1));
+    return ct < NT;
+}
+inline int xcd_grid_g(int MT, int NT, int gs) { return (8 * MT * (((NT + (8 << gs) - 1) / (8 << gs)))) << gs; }
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
 // same values, branch-free: both sides are evaluated and selected (epilogues that apply elu to 16-32 accumulator values per

@@ -128,33 +128,41 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&out)[MODE =
     for (int pl = 0; pl < (MODE == 2 ? 3 : 2); ++pl) out[pl] = __builtin_bit_cast(bf16x8, ((u32x4){p[pl][0], p[pl][1], p[pl][2], p[pl][3]}));
 }
 
-// the term products of one 32x32x16 block, small terms first (gemm_f32_mfma.h); FRESH: the first one starts from zero
-template <int MODE, bool FRESH>
+// the term products of one 32x32x16 block, small terms first (gemm_f32_mfma.h); FRESH: the first one starts from zero.
+// SWAP: the two fragments trade places in the instruction (the MFMA's A and B operand registers have the same shape: 8 consecutive
+// k of row / column lane & 31) -- the block comes out TRANSPOSED in the accumulators, lane = row of the a[] fragment, same bits.
+template <int MODE, bool FRESH, bool SWAP = false>
 __device__ __forceinline__ void mfma_terms(f32x16& c, const bf16x8 (&a)[MODE == 2 ? 3 : 2], const bf16x8 (&b)[MODE == 2 ? 3 : 2]) {
     f32x16 z;
 #pragma unroll
     for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    auto f16 = [](bf16x8 x, bf16x8 y, f32x16 acc) {
+        const f16x8 hx = __builtin_bit_cast(f16x8, x), hy = __builtin_bit_cast(f16x8, y);
+        return SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(hy, hx, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(hx, hy, acc, 0, 0, 0);
+    };
+    auto b16 = [](bf16x8 x, bf16x8 y, f32x16 acc) {
+        return SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
+    };
     if constexpr (MODE >= 3) {
-        auto h8 = [](bf16x8 v) { return __builtin_bit_cast(f16x8, v); };
         if constexpr (MODE == 4) {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a[1]), h8(b[1]), FRESH ? z : c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a[1]), h8(b[0]), c, 0, 0, 0);
+            c = f16(a[1], b[1], FRESH ? z : c);
+            c = f16(a[1], b[0], c);
         } else {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a[1]), h8(b[0]), FRESH ? z : c, 0, 0, 0);
+            c = f16(a[1], b[0], FRESH ? z : c);
         }
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a[0]), h8(b[1]), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(a[0]), h8(b[0]), c, 0, 0, 0);
+        c = f16(a[0], b[1], c);
+        c = f16(a[0], b[0], c);
     } else if constexpr (MODE == 1) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], FRESH ? z : c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+        c = b16(a[1], b[0], FRESH ? z : c);
+        c = b16(a[0], b[1], c);
+        c = b16(a[0], b[0], c);
     } else {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], FRESH ? z : c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+        c = b16(a[2], b[0], FRESH ? z : c);
+        c = b16(a[0], b[2], c);
+        c = b16(a[1], b[1], c);
+        c = b16(a[1], b[0], c);
+        c = b16(a[0], b[1], c);
+        c = b16(a[0], b[0], c);
     }
 }
 
@@ -205,9 +213,17 @@ constexpr int SP_TRACE_STEP = 5;
 struct SpNoPre {
     __device__ __forceinline__ void operator()() const {}
 };
-template <class T, int KT, class APlane, class BSlab, class Hooks, class BX, int ABL = 0, int SCHED = 0, class Pre = SpNoPre>
+// OPT bit 0 (SP_OPT_SWAP): the MFMA operands trade places -- the accumulators hold the TRANSPOSED tile: lane = row (wm TM + tm) 32 + l31 of
+//   the A operand, register r = column wn 32 + mfma_row(r, half) of the B operand (mlp.0 writes U^T point-major straight from them and
+//   sums the InstanceNorm statistics inside a lane).  The products and their order are unchanged: the same bits, transposed.
+// OPT bit 1 (SP_OPT_BT): the B operand is given TRANSPOSED in memory, B^T [column][k] fp32 with row stride ldb (floats): b_slab(kt) =
+//   &BT[col0][32 kt].  Its slab arrives as 128-byte LDS rows (one per column, chunk c of row r at c ^ ((r >> 1) & 7): the fp32 A rows of
+//   MODE 0) and a lane reads its 8 consecutive k with TWO 16-byte reads instead of eight 4-byte ones.
+constexpr int SP_OPT_SWAP = 1, SP_OPT_BT = 2;
+template <class T, int KT, class APlane, class BSlab, class Hooks, class BX, int ABL = 0, int SCHED = 0, class Pre = SpNoPre, int OPT = 0>
 __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* smem, APlane a_pl, BSlab b_slab, int ldb, Hooks& hooks,
                                                  BX& bx, SpTrace* tr_ = nullptr, Pre pre = Pre(), bool tron = false, int lda_bytes = 64) {
+    constexpr bool SWAP = (OPT & SP_OPT_SWAP) != 0, BT = (OPT & SP_OPT_BT) != 0;
     // lda_bytes: row stride of an A slab in bytes (slab-major 16-bit planes: 64; a row-major fp32 matrix: 4 x its leading dimension)
     // (profiling builds: the stamps go into the caller's SpTrace through a reference and a separate on/off flag -- a conditional pointer
     //  keeps the object in scratch memory and costs the traced kernel 50 spilled registers)
@@ -232,7 +248,10 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
     const unsigned a_lane = a_lane_row * (unsigned)lda_bytes + a_lane_chunk * 16;
     constexpr int LPR = BN / 4;        // lanes per k row of a B piece (16 B each)
     constexpr int KPP = 64 / LPR;      // k rows per B piece
-    const unsigned b_lane = (unsigned)(((lane / LPR) * ldb + (lane % LPR) * 4) * 4);
+    // (BT: a piece is 8 columns x 128 B of B^T; lane i supplies LDS chunk position i & 7 of row i >> 3, which holds source chunk
+    //  (i & 7) ^ ((row >> 1) & 7), (row >> 1) & 7 = 4 (piece & 1) | (i >> 4) inside an 8-row piece: the piece-parity bit is XORed in per piece)
+    const unsigned b_lane = BT ? (unsigned)((lane >> 3) * ldb * 4 + (((lane & 7) ^ ((lane >> 4) & 3)) * 16))
+                               : (unsigned)(((lane / LPR) * ldb + (lane % LPR) * 4) * 4);
     constexpr int RPP = T::BM / RPQ;   // A pieces per plane
     // pieces [j0, j1) of this wave's G pieces of slab kt
     auto issue_pieces = [&](int kt, int stage, int j0, int j1) {
@@ -250,7 +269,11 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
                        st + plane * T::A_PLANE_BYTES + qi * 1024);
             } else {
                 const int qb = q - T::NA;
-                glds16(reinterpret_cast<const char*>(b_slab(kt)) + (size_t)(qb * KPP) * ldb * 4 + b_lane, st + T::A_BYTES + qb * 1024);
+                if constexpr (BT)
+                    glds16(reinterpret_cast<const char*>(b_slab(kt)) + (size_t)(qb * 8) * ldb * 4 + (b_lane ^ ((unsigned)(qb & 1) * 64u)),
+                           st + T::A_BYTES + qb * 1024);
+                else
+                    glds16(reinterpret_cast<const char*>(b_slab(kt)) + (size_t)(qb * KPP) * ldb * 4 + b_lane, st + T::A_BYTES + qb * 1024);
             }
         }
     };
@@ -270,6 +293,14 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
             for (int e = 0; e < NCH; ++e) a_off[tm][s][e] = row * T::ROW_BYTES + ((((2 * s + half) * NCH + e) ^ x) * 16);
     }
     const int b_off = T::A_BYTES + ((8 * half) * BN + wn * 32 + l31) * 4;
+    int bt_off[2][2];   // BT: [k16 half][16-byte chunk] of the lane's column row
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = wn * 32 + l31;
+            bt_off[s][e] = T::A_BYTES + row * 128 + ((((2 * s + half) * 2 + e) ^ ((row >> 1) & 7)) * 16);
+        }
 
     bf16x8 Af[2][TM][PA * NCH];   // [k16 half][tm][plane] (fp32: the lane's 8 k as two 16-byte chunks)
     float Br[2][8];           // raw B values of the k16 half
@@ -285,8 +316,17 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
             for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(Br[P][j]));
             return;
         }
+        if constexpr (BT) {
+            const vf4 lo = *reinterpret_cast<const vf4*>(st + bt_off[P][0]), hi = *reinterpret_cast<const vf4*>(st + bt_off[P][1]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Br[P][j] = *reinterpret_cast<const float*>(st + b_off + (P * 16 + j) * BN * 4);
+            for (int j = 0; j < 4; ++j) {
+                Br[P][j] = lo[j];
+                Br[P][4 + j] = hi[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Br[P][j] = *reinterpret_cast<const float*>(st + b_off + (P * 16 + j) * BN * 4);
+        }
         if constexpr (BX::ON) bx.fetch(slab * BK + P * 16 + 8 * half, Bx[P]);
     };
     auto read_a = [&](int stage, auto Pc) {
@@ -358,12 +398,14 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
                         for (int r = 0; r < 16; ++r) c[r] = 0.f;
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], Bv[P][j], c, 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+                        c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(Bv[P][j], a0[j], c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], Bv[P][j], c, 0, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], Bv[P][4 + j], c, 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+                        c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(Bv[P][4 + j], a1[j], c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], Bv[P][4 + j], c, 0, 0, 0);
                     dst[tm] = c;
                 } else {
-                    mfma_terms<MODE, Hooks::template fresh<I, P>()>(dst[tm], Af[P][tm], Bf[P]);
+                    mfma_terms<MODE, Hooks::template fresh<I, P>(), SWAP>(dst[tm], Af[P][tm], Bf[P]);
                 }
             }
     };
@@ -519,9 +561,9 @@ __device__ __forceinline__ void gemm_mainloop_sp(f32x16 (&acc)[T::TM], char* sme
                 f32x16 z;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                dst[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, z, 0, 0, 0);
+                dst[tm] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, z, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, z, 0, 0, 0);
             } else {
-                dst[tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, dst[tm], 0, 0, 0);
+                dst[tm] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, dst[tm], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, dst[tm], 0, 0, 0);
             }
         };
         auto pair = [&](auto Pc, auto Qc) {

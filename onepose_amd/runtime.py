@@ -19,7 +19,17 @@ FRAMES_IN_FLIGHT = 4
 
 def configure_hip_queues(n=HW_QUEUES):
     """Export GPU_MAX_HW_QUEUES=n unless the caller already did; returns the value in force (str) or None when it is too late
-    (the runtime of this process is initialised and the variable was not set: the pool stays at the runtime's default)."""
+    (the runtime of this process is initialised and the variable was not set: the pool stays at the runtime's default) or when the
+    caller opted out.
+
+    This is a PROCESS-WIDE setting of the HIP runtime: it changes the queue pool of every other HIP user in the process.  Opt out with
+    ONEPOSE_AMD_NO_HIP_QUEUE_EXPORT=1 (the package then never touches the variable; StreamRing still works, its fourth stream shares a
+    hardware queue).  `import onepose_amd` must come before the first HIP call of the process for the export to take effect -- that
+    includes torch.cuda.is_available() / device_count(), which bring the runtime up without torch's own lazy init noticing: in that
+    case the value is exported and returned but ignored by the runtime (it cannot be detected from here; tests/conftest.py imports the
+    package first for that reason)."""
+    if os.environ.get("ONEPOSE_AMD_NO_HIP_QUEUE_EXPORT", "0") not in ("", "0"):
+        return None
     cur = os.environ.get("GPU_MAX_HW_QUEUES")
     if cur is not None:
         return cur

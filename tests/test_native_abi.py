@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_host_only_entry_points(lib):
     assert lib.gatsspg_version() >= 410
     big = 768 * 256 + 512 * 512 + 256 * 512           # the three big operators of an attention layer
-    assert lib.gatsspg_packed_weights_bytes() == (4 * (8 * (big + 768 + 512 + 256 + 4) + 4 * (512 + 256 * 256) + 256 * 256 + 256)   # + 4: fp16 plane scales per layer
+    assert lib.gatsspg_packed_weights_bytes() == (4 * (8 * (big + 768 + 512 + 256 + 8) + 4 * (512 + 256 * 256) + 256 * 256 + 256)   # + 8: fp16 plane scales (4) and the per-head row-L1 norms of the message half (4) per layer
                                                  
                                                   + 2 * 5 * 8 * big)   # + their three bf16 planes (hi / lo / lo2) and two fp16 planes
     small = lib.gatsspg_workspace_bytes(1, 500, 2000, 8)
