@@ -959,6 +959,21 @@ for prec in ('fp16x4', 'fp16x3'):
                 out[f'UT {prec} {shape}'] = [float((conf - ref[0]).abs().max()), float(ref[0].abs().max()), bool(torch.equal(m0, ref[1]))]
                 continue
             out[f'{prec} {shape} [{knobs}]'] = hashlib.sha256(conf.cpu().numpy().tobytes() + m0.cpu().numpy().tobytes()).hexdigest()
+# fp32 path: the register-direct stores of the Q tiles / mlp3 (FP32_DIRECT bits) against the LDS-staged ones
+m = GATsSuperGlue(HP, precision='fp32').eval()
+m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+m = m.to('cuda:0')
+for shape in ((1, 1000, 7000), (2, 300, 900)):
+    data = {k: torch.from_numpy(v).to('cuda:0') for k, v in synthetic.make_inputs(shape[0], shape[1], shape[2], 8, seed=11).items()}
+    for knobs in ('', 'FP32_DIRECT=0', 'FP32_DIRECT=1', 'FP32_DIRECT=2'):
+        for k in [k for k in os.environ if k.startswith('GATSSPG_')]:
+            del os.environ[k]
+        for kv in filter(None, knobs.split(',')):
+            a, b = kv.split('=')
+            os.environ['GATSSPG_' + a] = b
+        conf, m0, m1, s0, s1 = m.forward_batched(data)
+        torch.cuda.synchronize()
+        out[f'fp32 {shape} [{knobs}]'] = hashlib.sha256(conf.cpu().numpy().tobytes() + m0.cpu().numpy().tobytes()).hexdigest()
 print('SCHEDULE_PROBE ' + json.dumps(out))
 """
 
@@ -988,6 +1003,6 @@ def test_split_loop_schedules_are_bit_identical():
     groups = {}
     for key, digest in out.items():
         groups.setdefault(key.split(" [")[0], {})[key] = digest
-    assert len(groups) == 4
+    assert len(groups) == 6
     for g, members in groups.items():
         assert len(set(members.values())) == 1, f"{g}: schedules disagree bitwise: {members}"
