@@ -29,9 +29,11 @@ def parse(path, counter):
     for l in lines:
         if l[0] == "#":
             continue
-        name = l[0].split("<")[0]
-        if name in KEYS and KEYS[name] not in out:
-            out[KEYS[name]] = float(l[col])
+        for kname, key in KEYS.items():     # names are mangled and truncated (_ZN7gatsspg11mlp0_kernelINS_8GemmTile...): match the kernel's own name
+            if (f"{len(kname)}{kname}" in l[0] or l[0].split("<")[0] == kname) and key not in out:
+                if kname == "gats_leaf8x4_kernel" and "kernelILb0ELb0" not in l[0] and "<" not in l[0]:
+                    continue                 # the plain layer kernel, not the first layer's fused state load
+                out[key] = float(l[col])
     return out
 
 
