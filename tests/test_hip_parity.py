@@ -394,6 +394,24 @@ def test_trained_weights_vs_reference_golden(name, precision, trained_golden_met
         assert int((pred["matches0"] >= 0).sum()) == mc["valid_matches0"]
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x6", "fp16x4"])
+@pytest.mark.parametrize("b,n1,n2,num_leaf,noise", [(3, 129, 257, 8, (0.3, 0.5)), (1, 333, 1111, 3, (0.2, 0.3)), (2, 64, 2050, 8, (0.4, 0.6))])
+def test_trained_weights_vs_oracle_other_shapes(b, n1, n2, num_leaf, noise, precision):
+    """The trained network at shapes that have no reference-run golden (ragged sizes straddling every tile boundary, a batch of three,
+    num_leaf = 3, a 3D side of more than 32 column tiles next to a 2D side of one) against the oracle, which is itself pinned on the trained
+    goldens (tests/test_oracle_golden.py): conf within 1e-4 where it is O(1), every match of every sample identical."""
+    sd = synthetic.make_trained_state_dict()
+    data = synthetic.make_inputs(b, n1, n2, num_leaf, seed=77 + n1, planted=True, noise=noise)
+    _, conf_ref, inter = orc.forward(sd, data, HP, return_intermediates=True)
+    conf, m0, m1, s0, s1 = make_model(sd, HP, precision).forward_batched(to_dev(data))
+    err = maxdiff(conf.cpu().numpy(), conf_ref)
+    print(f"trained weights {b} x {n1} x {n2} (L = {num_leaf}) [{precision}]: max |conf - oracle| = {err:.3e}, largest conf {conf_ref.max():.3f}, "
+          f"valid matches of sample 0: {int((inter['batched']['matches0'][0] >= 0).sum())}")
+    assert err < CONF_ATOL and conf_ref.max() > 0.5
+    np.testing.assert_array_equal(m0.cpu().numpy(), inter["batched"]["matches0"])
+    np.testing.assert_array_equal(m1.cpu().numpy(), inter["batched"]["matches1"])
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fp16x4"])
 def test_trained_weights_database_cache_and_batch(precision, trained_golden_meta):
     """The trained network through the other entry points: the per-object database cache (bit-identical to the plain forward) and
