@@ -953,6 +953,8 @@ def main():
                 del tr
         except FileNotFoundError:
             parity_trained = None
+        except Exception as e:  # noqa: BLE001  (an extra check after the timed region must never cost the line itself)
+            parity_trained = {"error": f"{type(e).__name__}: {e}"}
     # the one (RCCL) collective: timings + the identity key of the device each rank drives (float64: keys are exact integers)
     per_rank = sharding.gather_metrics([K * runner.b, elapsed, solo if solo is not None else elapsed, dev_key], device=device)
     value, seconds = sharding.aggregate_throughput(per_rank.cpu())
