@@ -8,19 +8,26 @@ _native.LIB_PATH = build_ext.tuning_path(build_ext.LIB_PATH)
 import bench
 dev = torch.device("cuda:0")
 w = bench.Weights(dev); r = bench.Runner(dev, w)
+# --inflight N (round 5): N other frames are kept running on streams of their own while the traced launch executes (the protocol of bench.py's
+# `value`): what does the shader clock inside the kernel do when the socket sits at its power cap?
+NBG = int(sys.argv[sys.argv.index("--inflight") + 1]) if "--inflight" in sys.argv else 0
+bg = [bench.Runner(dev, w, r.shared_inputs, own_stream=True) for _ in range(NBG)]
 lib = w.engine.lib
 lib.gatsspg_debug_set_trace.argtypes = [ctypes.c_void_p]; lib.gatsspg_debug_set_trace.restype = None
 G = 8 * 4 * 16
 buf = torch.zeros(G * 8, dtype=torch.int64, device=dev)
 for i in range(5): r.step(i)
 torch.cuda.synchronize()
+if NBG:
+    for i in range(300):            # ~80 ms of background frames: the power manager has settled when the traced frame runs
+        bg[i % NBG].step(i)
 lib.gatsspg_debug_set_trace(buf.data_ptr())
 r.step(0)
+lib.gatsspg_debug_set_trace(None)   # (host-side: launches enqueued from here on are not traced)
 torch.cuda.synchronize()
-lib.gatsspg_debug_set_trace(None)
 t = buf.cpu().numpy().reshape(G, 8)
 t = t[t[:, 5] != 0]
-print("MLP0_TILE", os.environ.get("GATSSPG_MLP0_TILE"))
+print("MLP0_TILE", os.environ.get("GATSSPG_MLP0_TILE"), "| other frames in flight during the traced launch:", NBG)
 # the buffer holds the LAST mlp0 launch of the frame (every launch overwrites it)
 t0 = t[:, 2].min()
 ent, loop, end = (t[:, 2] - t0) / 100.0, (t[:, 4] - t0) / 100.0, (t[:, 5] - t0) / 100.0
