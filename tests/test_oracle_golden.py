@@ -141,10 +141,17 @@ def test_oracle_matches_reference_on_trained_weights(name, trained_golden_meta):
     assert float(planted.max()) > 0.9 and mc["planted_recovered_sample0"] >= 0.9 * mc["planted"]
 
 
-def test_trained_weights_are_a_full_network():
-    """Nothing on the forward path is zeroed or an identity (unlike the pass-through fixture), and every weight moved."""
+def test_trained_weights_are_a_full_network(trained_golden_meta):
+    """Nothing on the forward path is zeroed or an identity (unlike the pass-through fixture), and every weight moved; the fp32 bits
+    rebuilt from the committed factors on THIS machine are the ones the reference was run on (digest recorded by make_trained_golden.py)."""
+    import hashlib
     from onepose_amd import synthetic
     sd, base = synthetic.make_trained_state_dict(), synthetic.make_state_dict(synthetic.TRAINED_BASE_SEED)
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k]).tobytes())
+    assert h.hexdigest() == trained_golden_meta["state_dict_sha256"]
     for k, v in sd.items():
         assert v.dtype == np.float32 and v.shape == base[k].shape
         if k.startswith("kenc") or k == "bin_score":
