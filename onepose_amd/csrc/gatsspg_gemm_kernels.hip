@@ -114,6 +114,7 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel
     const TileSeg ts = tile_seg(L, c0, T::BN);
     constexpr int TS = T::BN + 4;  // LDS row stride (floats) of the [128][64] K/V tile: b128-read conflict-free
     float* Tl = smem;              // 128 * 68 floats = 34.8 KB <= main-loop LDS (reusable after its last barrier)
+    float opmx = 0.f;              // largest K (> 0) or |V| entry this wave holds: its rows are all K_h or all V_h
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm)
 #pragma unroll
@@ -124,8 +125,25 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel
             const float kf = elu1_select(v) + 1.f;
             v = row < 64 ? kf : v;
             v = col >= ts.valid ? 0.f : v;  // pad columns must not enter the sums (elu(0)+1 = 1)
+            opmx = fmaxf(opmx, fabsf(v));
             Tl[row * TS + col] = v;
         }
+    {   // operand maxima of the tile (slots [0..3] max K, [4..7] max |V|, as qkv_kv_sp_kernel writes them): only the fp16 modes' kv_final
+        // reads them, but a KV partial / database cache written in ANY arithmetic must be valid input for it (the C ABI does not tie a
+        // cache to the flags it was prepared with: round-5 advisor, medium) -- never uninitialised workspace
+        static_assert(T::WAVES_MN * T::KS == 8 || (T::WAVES_MN * T::KS == 4 && T::TM == 2), "8 waves: 0..3 hold K_h, 4..7 V_h; 4 waves: 0, 1 K_h, 2, 3 V_h");
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) opmx = fmaxf(opmx, __shfl_xor(opmx, o));
+        if (lane == 0) {
+            float* mx = kvpart + ((size_t)ct * H + h) * KVP + DH * DH + DH;
+            if constexpr (T::WAVES_MN * T::KS == 8) {
+                mx[wave] = opmx;
+            } else {
+                mx[wave] = wm == 0 ? opmx : 0.f;
+                mx[4 + wave] = wm == 0 ? 0.f : opmx;
+            }
+        }
+    }
     __syncthreads();
     if (wave < 4) {   // (an 8-wave workgroup leaves this short pass to its first four waves: same order of operations)
         // wave -> 32x32 quadrant (di, qi) of KV^T[d][q]; contraction over the 64 columns m (A operand = K rows, B operand = V rows)

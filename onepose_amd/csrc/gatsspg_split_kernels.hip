@@ -147,16 +147,21 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : 3)) void qkv_kv_sp_kernel
             opmx = fmaxf(opmx, fabsf(v));
             Tl[row * TS + col] = v;
         }
-    if constexpr (T::F16) {
+    {
         // operand maxima for kv_final's bound of the message operator (|KV_h| <= n_src max K max |V|): slots [0..3] max K, [4..7] max |V|,
-        // one per wave; a wave writes its own slot and zeroes its slot of the other kind
-        static_assert(T::WAVES == 4 && T::TM == 2, "waves 0, 1 hold K_h, waves 2, 3 hold V_h");
+        // one per wave; a wave writes its own slot and zeroes its slot of the other kind.  Written in every arithmetic (only the fp16
+        // modes' kv_final reads them, but a partial / database cache must never carry uninitialised slots: round-5 advisor)
+        static_assert((T::WAVES == 4 && T::TM == 2) || (T::WAVES == 8 && T::TM == 1), "4 waves: 0, 1 hold K_h, 2, 3 V_h; 8 waves: 0..3 K_h, 4..7 V_h");
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) opmx = fmaxf(opmx, __shfl_xor(opmx, o));
         if (lane == 0) {
             float* mx = kvpart + ((size_t)ct * H + h) * KVP + DH * DH + DH;
-            mx[wave] = wm == 0 ? opmx : 0.f;
-            mx[4 + wave] = wm == 0 ? 0.f : opmx;
+            if constexpr (T::WAVES == 8) {
+                mx[wave] = opmx;
+            } else {
+                mx[wave] = wm == 0 ? opmx : 0.f;
+                mx[4 + wave] = wm == 0 ? 0.f : opmx;
+            }
         }
     }
     __syncthreads();

@@ -18,16 +18,16 @@ FRAMES_IN_FLIGHT = 4
 
 
 def configure_hip_queues(n=HW_QUEUES):
-    """Export GPU_MAX_HW_QUEUES=n unless the caller already did; returns the value in force (str) or None when it is too late
+    """OPT-IN: export GPU_MAX_HW_QUEUES=n unless the caller already did; returns the value in force (str) or None when it is too late
     (the runtime of this process is initialised and the variable was not set: the pool stays at the runtime's default) or when the
-    caller opted out.
+    caller opted out.  Nothing calls this at import time; StreamRing() calls it (so does bench.py, explicitly, before `import torch`).
 
     This is a PROCESS-WIDE setting of the HIP runtime: it changes the queue pool of every other HIP user in the process.  Opt out with
-    ONEPOSE_AMD_NO_HIP_QUEUE_EXPORT=1 (the package then never touches the variable; StreamRing still works, its fourth stream shares a
-    hardware queue).  `import onepose_amd` must come before the first HIP call of the process for the export to take effect -- that
-    includes torch.cuda.is_available() / device_count(), which bring the runtime up without torch's own lazy init noticing: in that
-    case the value is exported and returned but ignored by the runtime (it cannot be detected from here; tests/conftest.py imports the
-    package first for that reason)."""
+    ONEPOSE_AMD_NO_HIP_QUEUE_EXPORT=1 (this function then never touches the variable; StreamRing still works, its fourth stream shares
+    a hardware queue).  The call must come before the first HIP call of the process to take effect -- that includes
+    torch.cuda.is_available() / device_count(), which bring the runtime up without torch's own lazy init noticing: in that case the
+    value is exported and returned but ignored by the runtime (it cannot be detected from here; tests/conftest.py calls this right
+    after importing the package for that reason)."""
     if os.environ.get("ONEPOSE_AMD_NO_HIP_QUEUE_EXPORT", "0") not in ("", "0"):
         return None
     cur = os.environ.get("GPU_MAX_HW_QUEUES")
@@ -46,6 +46,7 @@ class StreamRing:
     their workspaces per stream; every frame in flight needs outputs of its own, which the modules allocate per call)."""
 
     def __init__(self, device, n=FRAMES_IN_FLIGHT):
+        self.hw_queues = configure_hip_queues() if n >= 4 else os.environ.get("GPU_MAX_HW_QUEUES")   # before the first HIP call below, if it still can be
         if not torch.cuda.is_available():
             raise RuntimeError("StreamRing needs a ROCm GPU (there is no CPU path)")
         self.device = torch.device(device)

@@ -40,19 +40,32 @@ def parse(path, counter):
 def main():
     fetch, write = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE")
     git = sys.argv[sys.argv.index("--git") + 1] if "--git" in sys.argv else None
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = sys.argv[sys.argv.index("--file") + 1] if "--file" in sys.argv else os.path.join(ROOT, "profiles", "pmc_traffic.json")
     old = json.load(open(path)) if os.path.exists(path) else {}
+    if "--config" in sys.argv:
+        # a pass taken on another BASELINE config (python bench.py --config NAME): filed under _configs[NAME], the rest of the file is kept
+        name = sys.argv[sys.argv.index("--config") + 1]
+        entry = {"_source": {"csrc_sha": build_ext.source_hash(), "git_head": git, "passes": [os.path.basename(sys.argv[1]), os.path.basename(sys.argv[2])],
+                             "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --config {name} --steps 4 --warmup 2 --reps 1 "
+                                        "--min-timed-seconds 0 --streams 1 (tools/r06_collect.sh)"}}
+        for k in sorted(set(fetch) & set(write)):
+            entry[k] = {"FETCH_SIZE_KB": fetch[k], "WRITE_SIZE_KB": write[k], "bytes": int(round((2 * fetch[k] + write[k]) * 1024))}
+        old.setdefault("_configs", {})[name] = entry
+        json.dump(old, sys.stdout, indent=1)
+        return
     out = {"_comment": "HBM-side traffic per launch from rocprofv3 PMC passes: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, values in KB per "
                        "dispatch; on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads, so fetch bytes = 2 * FETCH_SIZE * 1024 "
                        "(MI355X_MICROARCH.md, HBM section); write bytes = WRITE_SIZE * 1024.  bench.py quotes these as static numbers and checks "
                        "_source.csrc_sha against the sources it runs (roofline.traffic_source).",
            "_source": {"csrc_sha": build_ext.source_hash(), "git_head": git, "passes": [os.path.basename(sys.argv[1]), os.path.basename(sys.argv[2])],
-                       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 6 --warmup 2 --reps 1 --streams 1 (tools/r05_final.sh)"}}
+                       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py --steps 6 --warmup 2 --reps 1 --min-timed-seconds 0 --streams 1 (tools/r06_collect.sh)"}}
     for k in sorted(set(fetch) & set(write)):
         out[k] = {"FETCH_SIZE_KB": fetch[k], "WRITE_SIZE_KB": write[k], "bytes": int(round((2 * fetch[k] + write[k]) * 1024))}
     for k, v in old.items():
         if k not in out and not k.startswith("_"):
             out[k] = dict(v, carried_over_from="the previous file (not covered by these passes)")
+    if "_configs" in old:
+        out["_configs"] = old["_configs"]
     json.dump(out, sys.stdout, indent=1)
 
 
