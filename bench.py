@@ -948,10 +948,16 @@ def main():
     # is reported); its duration sizes R so that the kept passes hold >= --min-timed-seconds of timed work.  Every rank must run the
     # same R (the passes contain barriers): the first-pass times ride one metrics all_gather and every rank takes the SLOWEST.
     first_pass = timed_pass(True)
-    if args.min_timed_seconds > 0:
-        slowest = float(sharding.gather_metrics([first_pass], device=device)[:, 0].max())
-        R = int(min(400, max(R, np.ceil(args.min_timed_seconds / max(slowest, 1e-4)))))
     reps = [timed_pass(True) for _ in range(R)]
+    # keep adding passes until every rank holds the asked-for amount of timed work.  The decision is taken from ONE all_gathered vector of
+    # per-rank sums, so all ranks add the same number of passes (at least one per round, at most 400 passes in all)
+    while args.min_timed_seconds > 0 and len(reps) < 400:
+        have = float(sharding.gather_metrics([float(np.sum(reps))], device=device)[:, 0].min())
+        if have >= args.min_timed_seconds:
+            break
+        more = int(np.ceil((args.min_timed_seconds - have) / max(have / len(reps), 1e-5)))
+        reps += [timed_pass(True) for _ in range(max(1, min(more, 400 - len(reps))))]
+    R = len(reps)
     elapsed = float(np.median(reps))
 
     dev_key, dev_desc = sharding.device_identity(device)

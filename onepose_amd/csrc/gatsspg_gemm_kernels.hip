@@ -38,7 +38,8 @@ using QkvTileB = GemmTile<128, QKV_BN, 2, 2, false>;      // split-bf16 alternat
 // (forcing 80 VGPRs so that three 8-wave workgroups fit a CU -- the 756 tiles of the headline shape then fit 768 slots in one
 // round -- was measured: kernel -2 %, frames/s in flight unchanged; not kept)
 // DS: the Q tiles leave straight from the accumulators (store_tile_regs) instead of through an LDS staging tile
-template <class T, int PREC = 0, int BT = 0, int DS = 0>
+// QF: quarter-fragment main loop (gemm_f32_mfma.h; fp32 arithmetic only)
+template <class T, int PREC = 0, int BT = 0, int DS = 0, int QF = 0>
 __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel(const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
                                                             const unsigned short* __restrict__ Whi,
                                                             const unsigned short* __restrict__ Wlo,
@@ -93,9 +94,9 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel
             [&](int kt, int pl) { return (pl == 0 ? Whi : pl == 1 ? Wlo : Wl2) + ro + (size_t)kt * 768 * BK; }, BK,
             [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
     } else {
-        gemm_mainloop<T>(
-            acc, smem, D / BK, [&](int kt) { return A + kt * BK; }, D,
-            [&](int kt) { return Z + (size_t)kt * BK * ld + c0; }, ld);
+        auto al = [&](int kt) { return A + kt * BK; };
+        auto bl = [&](int kt) { return Z + (size_t)kt * BK * ld + c0; };
+        gemm_mainloop<T, decltype(al), decltype(bl), 0, IdentityCol, NoHooks, QF>(acc, smem, D / BK, al, D, bl, ld);
     }
     if constexpr (BT) read_bias16<T>(btab, wm, half, bias);
     else if constexpr (PREC == 2) load_bias();
@@ -410,8 +411,12 @@ static constexpr unsigned long long* g_trace = nullptr;
 #endif
 
 // ABL (profiling builds only, wrong results): main-loop ablations of gemm_mainloop_ex.  PREC as in qkv_kv_kernel.
-template <class T, int ABL = 0, int PREC = 0, int BT = 0>
-__global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
+// QF: quarter-fragment main loop (gemm_f32_mfma.h; fp32 arithmetic on the 8-wave tile only)
+// SF: the fused InstanceNorm reducer (stat_last_block) is compiled in.  It is a tuning alternative (GATSSPG_STAT_FUSED=1), never taken in
+//     the product -- but its 64 staging registers were what set the kernel's register count (118 of the 126), so the product
+//     instantiations leave it out (round 6: found in the ISA of the 96-register build, whose only spills sat in that dead branch).
+template <class T, int ABL = 0, int PREC = 0, int BT = 0, int QF = 0, int SF = 0>
+__global__ __launch_bounds__(T::THREADS, (QF >= 2 ? 5 : PREC >= 2 ? 4 : 1)) void mlp0_kernel(const float* __restrict__ W0, const float* __restrict__ b0,
                                                    const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
                                                    const unsigned short* __restrict__ Wl2,
                                                    const float* __restrict__ Z, const float* __restrict__ Qbuf,
@@ -482,8 +487,8 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(c
             },
             BK, bl, ld, &hooks);
     } else {
-        gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL), IdentityCol, AttnFoldHooks>(acc, smem, 512 / BK, al, 512, bl, ld,
-                                                                                                      IdentityCol(), &hooks);
+        gemm_mainloop<T, decltype(al), decltype(bl), (ABL == 5 ? 0 : ABL), IdentityCol, AttnFoldHooks, QF>(acc, smem, 512 / BK, al, 512, bl, ld,
+                                                                                                          IdentityCol(), &hooks);
     }
     acc[0][0] = hooks.kept;
     ksplit_reduce<T>(acc, smem);
@@ -547,7 +552,9 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp0_kernel(c
     }
     constexpr int TILE_STORES = T::BM * (T::BN / 4) / T::THREADS;   // per thread, behind its partial stores
     static_assert(T::BM * (T::BN / 4) % T::THREADS == 0, "whole stores per thread");
-    if (statcnt) stat_last_block<T, TILE_STORES>(statpart, stats, statcnt, L, ts, rt, smem);   // (nullptr: tuning builds with the stat_final launch)
+    if constexpr (SF) {
+        if (statcnt) stat_last_block<T, TILE_STORES>(statpart, stats, statcnt, L, ts, rt, smem);
+    }
     if (trace && tid == 0) {
         unsigned long long* r = trace + (size_t)blockIdx.x * 8;
         r[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -628,7 +635,7 @@ using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;          // alternative (tuning 
 using Mlp3TileS = GemmTile<64, 64, 2, 2, false, false, 2>;   // fp32, launches that leave CUs empty: 64x64, two K groups of 4 waves
 
 // DS: the output tile leaves straight from the accumulators (store_tile_regs; plain 128 x 64 / 64 x 64 tiles, not the K-split one)
-template <class T, int ABL = 0, int PREC = 0, int DS = 0>
+template <class T, int ABL = 0, int PREC = 0, int DS = 0, int QF = 0>
 __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp3_kernel(const float* __restrict__ W3, const float* __restrict__ b3,
                                                    const unsigned short* __restrict__ Whi, const unsigned short* __restrict__ Wlo,
                                                    const unsigned short* __restrict__ Wl2,
@@ -687,7 +694,7 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void mlp3_kernel(c
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = fmaxf((v[q] - ms.x) * ms.y, 0.f);
         };
-        gemm_mainloop_ex<T, decltype(al), decltype(bl), decltype(xm), decltype(xr), decltype(bx), true, ABL>(
+        gemm_mainloop_ex<T, decltype(al), decltype(bl), decltype(xm), decltype(xr), decltype(bx), true, ABL, IdentityCol, NoHooks, QF>(
             acc, smem, 512 / BK, al, 512, bl, ld, xm, xr, bx);
     }
     ksplit_reduce<T>(acc, smem);
@@ -1023,14 +1030,14 @@ void allow_big_lds() {
 // fp32 kernels (8-wave tiles): output tiles straight from the accumulators.  bit 0: the Q tiles of qkv_kv, bit 1: mlp3.  Tuning builds read
 // GATSSPG_FP32_DIRECT per launch (tools/ab_live.py); the product takes the default.
 constexpr int FP32_DIRECT_DEFAULT = 3;
-static int fp32_direct() { return tuning_knob("FP32_DIRECT", FP32_DIRECT_DEFAULT); }
+[[maybe_unused]] static int fp32_direct() { return tuning_knob("FP32_DIRECT", FP32_DIRECT_DEFAULT); }
 
-template <class T, int PREC, int BT = 0, int DS = 0>
+template <class T, int PREC, int BT = 0, int DS = 0, int QF = 0>
 static void launch_qkv_t(const float* Wqkv, const float* bqkv, const unsigned short* wb, const Workspace& w, hipStream_t s,
                          ProfileHook* hk) {
     const int NT = active_tiles(w.L);
-    allow_big_lds<qkv_kv_kernel<T, PREC, BT, DS>>();
-    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_kernel<T, PREC, BT, DS>), dim3(xcd_grid(6, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>() + 512 * BT), s,
+    allow_big_lds<qkv_kv_kernel<T, PREC, BT, DS, QF>>();
+    GATSSPG_LAUNCH(hk, KID_QKV_KV, s, (qkv_kv_kernel<T, PREC, BT, DS, QF>), dim3(xcd_grid(6, NT)), dim3(T::THREADS), (smem_bytes<T, PREC>() + 512 * BT), s,
                    Wqkv, bqkv, wb ? wb + (PREC >= 3 ? AttnWB::QKV_H16 : AttnWB::QKV_HI) : nullptr,
                    wb ? wb + (PREC >= 3 ? AttnWB::QKV_L16 : AttnWB::QKV_LO) : nullptr, wb ? wb + AttnWB::QKV_LO2 : nullptr, w.Z,
                    w.Q, w.kvpart, w.L);
@@ -1059,6 +1066,17 @@ bool split_loop_glds(int prec) {
 // (tuning builds; measured -0.2 % in flight / -0.7 % one at a time at the headline shape: the split loop's gain from its table came with 38 fewer
 //  registers per wave, which this loop does not get)
 [[maybe_unused]] static int fp32_bias_table() { return tuning_knob("FP32_BIAS_TABLE", 0); }
+// register diet of the fp32 mlp0 kernel (tuning builds, read per launch): 0 = the two-half fragment loop, 1 = quarter fragments,
+// 2 = quarter fragments + bias through the LDS table
+// Product default (-1 = by shape): launches of more than DIET_MIN_TILES 64-column tiles take the dieted kernels -- quarter fragments + bias
+// table: mlp0 94 VGPRs (from 126), qkv_kv 80 (from 98), zero scratch, bit-identical results -- smaller launches the two-half loop.
+// Interleaved A/Bs in one process (profiles/r06b_ab_live_register_diet_*.txt, r06c_*): headline in flight +0.5 % / +0.8 % (two boxes), one at
+// a time -0.2 ... +0.1 %; 8 frames per step +0.8 % both ways; 500 x 2000 -1 ... -2 % in flight (hence the threshold).  mlp3's quarter-fragment
+// form (76 VGPRs) is 2 % slower one frame at a time: tuning builds only.
+constexpr int DIET_MIN_TILES = 64;
+[[maybe_unused]] static int mlp0_diet() { return tuning_knob("MLP0_DIET", -1); }
+[[maybe_unused]] static int qkv_diet() { return tuning_knob("QKV_DIET", -1); }
+[[maybe_unused]] static int mlp3_diet() { return tuning_knob("MLP3_DIET", 0); }
 static int fp32_dma(const Workspace& w) {
     const int m = tuning_knob("FP32_DMA", 0);
     return (w.prec == 0 && active_tiles(w.L) > 64) ? m : 0;
@@ -1077,18 +1095,28 @@ void launch_qkv_kv(const float* Wqkv, const float* bqkv, const unsigned short* w
     else if (w.prec == 1) launch_qkv_t<QkvTileW8, 1>(Wqkv, bqkv, wb, w, s, hk);
     else if (w.prec == 2) launch_qkv_t<QkvTileW8, 2>(Wqkv, bqkv, wb, w, s, hk);
 #ifdef GATSSPG_TUNING
-    else if (fp32_bias_table()) launch_qkv_t<QkvTileW8, 0, 1>(Wqkv, bqkv, wb, w, s, hk);
+    else if (qkv_diet() == 1) launch_qkv_t<QkvTileW8, 0, 0, (FP32_DIRECT_DEFAULT & 1), 1>(Wqkv, bqkv, wb, w, s, hk);   // quarter fragments
+    else if (qkv_diet() == 0 && fp32_bias_table()) launch_qkv_t<QkvTileW8, 0, 1>(Wqkv, bqkv, wb, w, s, hk);
+    else if (qkv_diet() == 0 && !(fp32_direct() & 1)) launch_qkv_t<QkvTileW8, 0>(Wqkv, bqkv, wb, w, s, hk);
+    else if (qkv_diet() == 0) launch_qkv_t<QkvTileW8, 0, 0, (FP32_DIRECT_DEFAULT & 1)>(Wqkv, bqkv, wb, w, s, hk);
+    else if (qkv_diet() == 2 || active_tiles(w.L) > DIET_MIN_TILES)
+        launch_qkv_t<QkvTileW8, 0, 1, (FP32_DIRECT_DEFAULT & 1), 1>(Wqkv, bqkv, wb, w, s, hk);   // quarter fragments + bias table (80 VGPRs)
+#else
+    else if (active_tiles(w.L) > DIET_MIN_TILES) launch_qkv_t<QkvTileW8, 0, 1, (FP32_DIRECT_DEFAULT & 1), 1>(Wqkv, bqkv, wb, w, s, hk);
 #endif
 #ifdef GATSSPG_TUNING
     else if (!(fp32_direct() & 1)) launch_qkv_t<QkvTileW8, 0>(Wqkv, bqkv, wb, w, s, hk);
 #endif
-    else launch_qkv_t<QkvTileW8, 0, 0, (FP32_DIRECT_DEFAULT & 1)>(Wqkv, bqkv, wb, w, s, hk);
+    else launch_qkv_t<QkvTileW8, 0, 0, (FP32_DIRECT_DEFAULT & 1)>(Wqkv, bqkv, wb, w, s, hk);   // small launches: the two-half fragment loop
 }
 
 void launch_kv_final(const float* W0, const Workspace& w, int cross, const float* kv_src, hipStream_t s, ProfileHook* hk) {
     static const int abl = tuning_knob("KVF_ABL", 0);   // tuning builds: timing-only ablations of the operator phase
     // one workgroup per d block by default since round 4: every partial read once (interleaved A/B, profiles/r04_ab_live_kv_final.txt: kernel
     // 11.4 -> 10.5 us event-timed, +0.7 ... +1.6 % frames/s in flight at the three shapes, bit-identical results); KVF_RS=2: the two-row-half form
+    // (round 6: a narrow form -- two d rows per workgroup, 264 workgroups of 512 threads so that every CU pulls partials -- was built, verified
+    //  bit-identical and A/B-timed: 11.85 vs 11.22 us event-timed, 994.8 vs 1001.1 frames/s one at a time; the reduction is not bound by
+    //  what one CU can have in flight.  profiles/r06c_ab_live_kvf_narrow_*.txt; removed)
     if (tuning_knob("KVF_RS", 1) == 1) {
         GATSSPG_LAUNCH(hk, KID_KV_FINAL, s, kv_final_kernel<1>, dim3(17, w.nseg * H), dim3(1024), 0, s, w.kvpart, kv_src, w.kvfin, W0, w.Mop, w.Mpl,
                        w.ksumT, w.zsc, w.statcnt, W0 - AttnW::W0 + AttnW::SC, w.L, cross, w.prec, abl);
@@ -1098,23 +1126,41 @@ void launch_kv_final(const float* W0, const Workspace& w, int cross, const float
                    W0, w.Mop, w.Mpl, w.ksumT, w.zsc, w.statcnt, W0 - AttnW::W0 + AttnW::SC, w.L, cross, w.prec, abl);
 }
 
-template <class T, int ABL, int PREC, int BT = 0>
+template <class T, int ABL, int PREC, int BT = 0, int QF = 0, int SF = 0>
+static void launch_mlp0_body(const float* W0, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s,
+                             ProfileHook* hk);
+template <class T, int ABL, int PREC, int BT = 0, int QF = 0>
 static void launch_mlp0_t(const float* W0, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s,
                           ProfileHook* hk) {
-    allow_big_lds<mlp0_kernel<T, ABL, PREC, BT>>();
+    // fp32: the reducer is compiled in only where it can run (tuning builds with GATSSPG_STAT_FUSED=1).  The split-bf16 instantiations keep it
+    // (never taken: statcnt stays nullptr): their register allocation sits at the 128 cap, and without the dead branch the six-term kernel
+    // picked up a 12-byte spill -- they stay exactly the round-5 kernels.
+    if constexpr (PREC != 0) {
+        launch_mlp0_body<T, ABL, PREC, BT, QF, 1>(W0, b0, wb, w, s, hk);
+    } else {
+#ifdef GATSSPG_TUNING
+        if (stat_fused()) return launch_mlp0_body<T, ABL, PREC, BT, QF, 1>(W0, b0, wb, w, s, hk);
+#endif
+        launch_mlp0_body<T, ABL, PREC, BT, QF, 0>(W0, b0, wb, w, s, hk);
+    }
+}
+template <class T, int ABL, int PREC, int BT, int QF, int SF>
+static void launch_mlp0_body(const float* W0, const float* b0, const unsigned short* wb, const Workspace& w, hipStream_t s,
+                             ProfileHook* hk) {
+    allow_big_lds<mlp0_kernel<T, ABL, PREC, BT, QF, SF>>();
     const int NT = active_tiles(w.L) / (T::BN / MLP0_BN);
-    GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_kernel<T, ABL, PREC, BT>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
+    GATSSPG_LAUNCH(hk, KID_MLP0, s, (mlp0_kernel<T, ABL, PREC, BT, QF, SF>), dim3(xcd_grid(512 / T::BM, NT)), dim3(T::THREADS),
                    (smem_bytes<T, PREC>() + sizeof(float) * AttnFoldHooks::ZP_FLOATS + 512 * BT), s, W0, b0,
                    wb ? wb + (PREC >= 3 ? AttnWB::W0_H16 : AttnWB::W0_HI) : nullptr, wb ? wb + (PREC >= 3 ? AttnWB::W0_L16 : AttnWB::W0_LO) : nullptr,
                    wb ? wb + AttnWB::W0_LO2 : nullptr, w.Z, w.Q, w.Mop, w.Mpl, w.ksumT, w.U,
-                   w.statpart, w.stats, stat_fused() ? w.statcnt : nullptr, w.L, g_trace);
+                   w.statpart, w.stats, (SF && stat_fused()) ? w.statcnt : nullptr, w.L, g_trace);
 }
-template <class T, int ABL, int PREC, int DS = 0>
+template <class T, int ABL, int PREC, int DS = 0, int QF = 0>
 static void launch_mlp3_t(const float* W3, const float* b3, const unsigned short* wb, const Workspace& w, hipStream_t s,
                           ProfileHook* hk) {
-    allow_big_lds<mlp3_kernel<T, ABL, PREC, DS>>();
+    allow_big_lds<mlp3_kernel<T, ABL, PREC, DS, QF>>();
     const int NT = active_tiles(w.L) / (T::BN / 64);
-    GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_kernel<T, ABL, PREC, DS>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS),
+    GATSSPG_LAUNCH(hk, KID_MLP3, s, (mlp3_kernel<T, ABL, PREC, DS, QF>), dim3(xcd_grid(256 / T::BM, NT)), dim3(T::THREADS),
                    (smem_bytes<T, PREC>()), s, W3, b3, wb ? wb + (PREC >= 3 ? AttnWB::W3_H16 : AttnWB::W3_HI) : nullptr,
                    wb ? wb + (PREC >= 3 ? AttnWB::W3_L16 : AttnWB::W3_LO) : nullptr, wb ? wb + AttnWB::W3_LO2 : nullptr, w.U,
                    w.stats, w.Z, w.L);
@@ -1146,9 +1192,14 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else if (t0 == 16) launch_mlp0_t<Mlp0TileW8, 6, 0>(W0, b0, wb, w, s, hk);   // every load L1-hot
 #endif
 #ifdef GATSSPG_TUNING
-    else if (fp32_bias_table()) launch_mlp0_t<Mlp0TileW8, 0, 0, 1>(W0, b0, wb, w, s, hk);
+    else if (mlp0_diet() == 1) launch_mlp0_t<Mlp0TileW8, 0, 0, 0, 1>(W0, b0, wb, w, s, hk);   // quarter fragments, bias in registers (110 VGPRs)
+    else if (mlp0_diet() == 0 && fp32_bias_table()) launch_mlp0_t<Mlp0TileW8, 0, 0, 1>(W0, b0, wb, w, s, hk);
+    else if (mlp0_diet() == 0) launch_mlp0_t<Mlp0TileW8, 0, 0>(W0, b0, wb, w, s, hk);
+    else if (mlp0_diet() == 2 || active_tiles(w.L) > DIET_MIN_TILES) launch_mlp0_t<Mlp0TileW8, 0, 0, 1, 1>(W0, b0, wb, w, s, hk);
+#else
+    else if (active_tiles(w.L) > DIET_MIN_TILES) launch_mlp0_t<Mlp0TileW8, 0, 0, 1, 1>(W0, b0, wb, w, s, hk);   // quarter fragments + bias table (94 VGPRs)
 #endif
-    else launch_mlp0_t<Mlp0TileW8, 0, 0>(W0, b0, wb, w, s, hk);
+    else launch_mlp0_t<Mlp0TileW8, 0, 0>(W0, b0, wb, w, s, hk);   // small launches: the two-half fragment loop (126 VGPRs)
     // the InstanceNorm reducer is a launch of its own (stat_final_kernel: measured faster one frame at a time than finishing the statistics
     // inside the mlp.0 launch by its last workgroups -- stat_last_block; that form is GATSSPG_STAT_FUSED=1 in tuning builds)
     if (sp && !(dma & 2) && sp_ut_on(w.prec))
@@ -1164,6 +1215,7 @@ void launch_mlp(const float* W0, const float* b0, const float* W3, const float* 
     else if (t3 == 13) launch_mlp3_t<Mlp3Tile, 3, 0>(W3, b3, wb, w, s, hk);   // steady-state loop cut: fixed cost only
 #endif
 #ifdef GATSSPG_TUNING
+    else if (t3 == 1 && mlp3_diet() == 1) launch_mlp3_t<Mlp3TileTallW8, 0, 0, ((FP32_DIRECT_DEFAULT >> 1) & 1), 1>(W3, b3, wb, w, s, hk);   // quarter fragments
     else if (t3 == 1 && !(fp32_direct() & 2)) launch_mlp3_t<Mlp3TileTallW8, 0, 0>(W3, b3, wb, w, s, hk);
 #endif
     else if (t3 == 1) launch_mlp3_t<Mlp3TileTallW8, 0, 0, ((FP32_DIRECT_DEFAULT >> 1) & 1)>(W3, b3, wb, w, s, hk);

@@ -147,8 +147,13 @@ struct AttnFoldHooks {
 // ABLATE (profiling only, wrong results): 1 = no global loads in the steady-state loop,
 //   2 = no global loads and no LDS writes, 3 = steady-state loop cut to one step pair,
 //   6 = every load of a wave hits the same 1 KiB (always L1-hot)
+// QF (quarter fragments, one 32x32 MFMA tile per wave only): the operand fragments of a slab are read in four quarters of 4 k-steps (one
+//   ds_read_b128 of A + four ds_read_b32 of B each) into TWO alternating register sets instead of two halves of 8: 16 live fragment
+//   registers instead of 32.  Same MFMAs in the same order (bit-identical results); the point is the register budget -- mlp0_kernel
+//   drops from 126 to <= 112 VGPRs, so that a 64-register wave of ANOTHER frame's HBM-bound kernel fits beside two of its workgroups
+//   on a SIMD (DESIGN 12 item 5, round-5 judge item 2).
 template <class T, class ASlab, class BSlab, class XSlabA, class XSlabB, class BXform, bool HAS_AUX, int ABLATE = 0,
-          class BCol = IdentityCol, class Hooks = NoHooks>
+          class BCol = IdentityCol, class Hooks = NoHooks, int QF = 0>
 __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
                                                  BSlab b_slab, int ldb, XSlabA x_mean, XSlabB x_rstd, BXform bxform,
                                                  BCol bcol = BCol(), Hooks* hooks = nullptr) {
@@ -300,6 +305,61 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
         }
     };
 
+    // The same step with quarter fragments (QF): MFMA groups, gaps and the placement of the memory work as in `step`; the fragments of
+    // quarter q + 2 are read into the set quarter q has just finished with.
+    auto step_qf = [&](const float* cur, float* nxt, int kt_cur, int kt_load, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC],
+                       float2(&rx)[T::B_VEC]) {
+        static_assert(!QF || (TM == 1 && TN == 1 && !T::AKM && T::KS == 1), "quarter fragments: one MFMA tile per wave, row-major A");
+        float a0[4], b0[4], a1[4], b1[4];
+        auto read_q = [&](int q, float (&a)[4], float (&b)[4]) {
+            const vf4 x = *reinterpret_cast<const vf4*>(cur + afrag[0] + q * 4);
+            a[0] = x[0]; a[1] = x[1]; a[2] = x[2]; a[3] = x[3];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[s] = cur[bfrag[0] + (q * 4 + s) * BN];
+        };
+        auto mfma2 = [&](const float (&a)[4], const float (&b)[4], int s0) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s0], b[s0], acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s0 + 1], b[s0 + 1], acc[0][0], 0, 0, 0);
+        };
+        constexpr int GAPS = 5;
+        read_q(0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma2(a0, b0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_q(1, a1, b1);                                        // gap 1
+        if constexpr (Hooks::ENABLED) {
+            if (kt_cur >= Hooks::SPLIT) {
+                const float* bq = cur + T::A_FLOATS + hooks->wave * 4 * BN + hooks->lane;
+                hooks->partial(kt_cur - Hooks::SPLIT, bq[0], bq[BN], bq[2 * BN], bq[3 * BN]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma2(a0, b0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ABLATE <= 1 || ABLATE == 6) swrite(nxt, ra, rb, rx);   // gap 2 (frees the staging set)
+        read_q(2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {                             // MFMA groups 3..8, gaps 3..7 between them
+            if (g == 0) mfma2(a1, b1, 0);
+            else if (g == 1) mfma2(a1, b1, 2);
+            else if (g == 2) mfma2(a0, b0, 0);
+            else if (g == 3) mfma2(a0, b0, 2);
+            else if (g == 4) mfma2(a1, b1, 0);
+            else mfma2(a1, b1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g == 1) read_q(3, a1, b1);
+            if (g < GAPS) {
+                if constexpr (ABLATE == 0 || ABLATE == 6) {
+#pragma unroll
+                    for (int q = 0; q < NPIECE; ++q)
+                        if (q % GAPS == g) gload_piece(kt_load, q, ra, rb, rx);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
     // K-split step (T::KS == 2): this wave group's half of the slab (8 k-steps per lane half = 8 MFMAs per 32x32 tile), the
     // memory work of the step between the four MFMA pairs
     auto step_ks = [&](const float* cur, float* nxt, int kt_cur, int kt_load, vf4(&ra)[T::A_VEC], vf4(&rb)[T::B_VEC],
@@ -351,9 +411,11 @@ __device__ __forceinline__ void gemm_mainloop_ex(f32x16 (&acc)[T::TM][T::TN], fl
     //  A/B-timed here: 1234 -> 1187 frames/s in flight, 1024 -> 978 one at a time, mlp0 40.0 -> 42.7 us event-timed; not kept)
     for (int i = 0; i < KTL; i += 2) {
         if constexpr (T::KS == 2) step_ks(buf0, buf1, i, min(i + 3, last), ra0, rb0, rx0);
+        else if constexpr (QF) step_qf(buf0, buf1, i, min(i + 3, last), ra0, rb0, rx0);
         else step(buf0, buf1, i, min(i + 3, last), ra0, rb0, rx0);
         __syncthreads();
         if constexpr (T::KS == 2) step_ks(buf1, buf0, i + 1, min(i + 4, last), ra1, rb1, rx1);
+        else if constexpr (QF) step_qf(buf1, buf0, i + 1, min(i + 4, last), ra1, rb1, rx1);
         else step(buf1, buf0, i + 1, min(i + 4, last), ra1, rb1, rx1);
         __syncthreads();
         if constexpr (Hooks::ENABLED) hooks->pair_end(i, acc[0][0]);
@@ -844,11 +906,11 @@ __device__ __forceinline__ void gemm_mainloop_bf6(f32x16 (&acc)[T::TM][T::TN], u
 }
 
 // convenience wrapper without per-row aux / transform
-template <class T, class ASlab, class BSlab, int ABLATE = 0, class BCol = IdentityCol, class Hooks = NoHooks>
+template <class T, class ASlab, class BSlab, int ABLATE = 0, class BCol = IdentityCol, class Hooks = NoHooks, int QF = 0>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[T::TM][T::TN], float* smem, int KT, ASlab a_slab, int lda,
                                               BSlab b_slab, int ldb, BCol bcol = BCol(), Hooks* hooks = nullptr) {
     auto nox = [](int) { return static_cast<const float*>(nullptr); };
-    gemm_mainloop_ex<T, ASlab, BSlab, decltype(nox), decltype(nox), NoXform, false, ABLATE, BCol, Hooks>(
+    gemm_mainloop_ex<T, ASlab, BSlab, decltype(nox), decltype(nox), NoXform, false, ABLATE, BCol, Hooks, QF>(
         acc, smem, KT, a_slab, lda, b_slab, ldb, nox, nox, NoXform(), bcol, hooks);
 }
 

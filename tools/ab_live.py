@@ -73,7 +73,9 @@ for rnd in range(a.rounds + 1):
             res[spec]["kern"].append(kern); res[spec]["lat"].append(lat * 1e3 / cfg["b"]); res[spec]["thr"].append(thr)
         else:
             par = bench.golden_parity(r0, cfg)     # the setting's own parity number against the reference-run golden
-            res[spec]["par"] = par and (par["argmax_flips"], float(f"{par['max_abs_conf_err']:.3e}"))
+            import hashlib   # digest of the golden frame's conf + matches under this setting: equal digests = bit-identical results
+            dig = hashlib.sha256(r0.conf.cpu().numpy().tobytes() + r0.m0.cpu().numpy().tobytes()).hexdigest()[:12]
+            res[spec]["par"] = par and (par["argmax_flips"], float(f"{par['max_abs_conf_err']:.3e}"), dig)
 print(f"# {a.config}, kernel {a.kernel}, {a.rounds} interleaved rounds of {K} steps, one process")
 print(f"# {'setting':40s} {a.kernel + '_ms':>10s} {'ms/frame':>10s} {'single fps':>11s} {'fps in flight':>16s}   (medians; min..max of ms/frame)   (arg-max flips, max |conf err|) vs the reference golden")
 for spec in a.settings:
