@@ -1114,6 +1114,13 @@ void launch_kv_final(const float* W0, const Workspace& w, int cross, const float
     static const int abl = tuning_knob("KVF_ABL", 0);   // tuning builds: timing-only ablations of the operator phase
     // one workgroup per d block by default since round 4: every partial read once (interleaved A/B, profiles/r04_ab_live_kv_final.txt: kernel
     // 11.4 -> 10.5 us event-timed, +0.7 ... +1.6 % frames/s in flight at the three shapes, bit-identical results); KVF_RS=2: the two-row-half form
+    // (round 6, second experiment: the projection SPLIT in two launches -- first the four [K_h ; V_h] row tiles (504 workgroups: one round of
+    //  the 512 resident slots), then ONE grid holding the two Q row tiles and kv_final's workgroups in the narrow 512-thread form -- so that the
+    //  reduction + message operator runs beside the Q tiles instead of in front of mlp.0.  Bit-identical.  Event-timed at the headline shape:
+    //  27.5 + 21.6 us against 39.2 + 11.8 us for the classic pair, frame 0.9948 vs 0.9942 ms, 1264 vs 1266 frames/s in flight; 500 x 2000:
+    //  0.626 vs 0.567 ms.  One Q tile per CU is a single workgroup's dependent chain (17 us for 8 slabs), not a matrix-pipe load: what the
+    //  hidden kv_final saves the lonely Q tiles give back.  With kv_final's workgroups FIRST in the grid they took both slots of half the
+    //  CUs and the Q tiles paired up on the rest: 1.046 ms.  profiles/r06e_*, r06f_*; removed.)
     // (round 6: a narrow form -- two d rows per workgroup, 264 workgroups of 512 threads so that every CU pulls partials -- was built, verified
     //  bit-identical and A/B-timed: 11.85 vs 11.22 us event-timed, 994.8 vs 1001.1 frames/s one at a time; the reduction is not bound by
     //  what one CU can have in flight.  profiles/r06c_ab_live_kvf_narrow_*.txt; removed)
