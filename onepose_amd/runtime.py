@@ -45,13 +45,26 @@ class StreamRing:
     """n HIP streams dealt round-robin: ``with ring.next(): pred, conf = model(data)`` keeps n frames in flight (the modules cache
     their workspaces per stream; every frame in flight needs outputs of its own, which the modules allocate per call)."""
 
-    def __init__(self, device, n=FRAMES_IN_FLIGHT):
+    def __init__(self, device, n=FRAMES_IN_FLIGHT, streams=None):
+        """streams: optional list of existing torch.cuda.Stream objects to deal frames over instead of creating n new ones (a process that
+        already owns per-frame streams should reuse them: the runtime maps streams onto its hardware queues in creation order, and two busy
+        streams that land on one queue serialise)."""
         self.hw_queues = configure_hip_queues() if n >= 4 else os.environ.get("GPU_MAX_HW_QUEUES")   # before the first HIP call below, if it still can be
         if not torch.cuda.is_available():
             raise RuntimeError("StreamRing needs a ROCm GPU (there is no CPU path)")
         self.device = torch.device(device)
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(n)]
+        self.streams = list(streams) if streams is not None else [torch.cuda.Stream(self.device) for _ in range(n)]
         self._i = 0
+
+    _shared = {}
+
+    @classmethod
+    def shared(cls, device, n=FRAMES_IN_FLIGHT):
+        """The process-wide ring of `device`: every component that overlaps frames should deal them over ONE set of streams (see __init__)."""
+        key = (str(torch.device(device)), n)
+        if key not in cls._shared:
+            cls._shared[key] = cls(device, n)
+        return cls._shared[key]
 
     def next(self):
         s = self.streams[self._i % len(self.streams)]

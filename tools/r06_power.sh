@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 5: what the power manager does under the matcher's kernels -- rocm-smi socket power / clocks sampled while bench.py runs
-# (usage: tools/r05_power.sh; writes gpurun_out/r05p/)
+# round 6 (same protocol as round 5): what the power manager does under the matcher's kernels -- rocm-smi socket power / clocks sampled while bench.py runs
+# (usage: tools/r06_power.sh; writes gpurun_out/r06p/)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r05p; mkdir -p $O
+O=$R/gpurun_out/r06p; mkdir -p $O
 cd $R
 (rocm-smi --showmaxpower; rocm-smi --showpower --showclocks --showperflevel; amd-smi static --limit 2>/dev/null | head -30) > $O/smi_idle.txt 2>&1
 sample() {   # $1 tag, rest: bench flags
@@ -27,4 +27,6 @@ sample fp16x4 --config fp16x4 --steps 9000
 sample fp16x4_s1 --config fp16x4 --steps 9000 --streams 1
 sample bf16x6 --config bf16x6 --steps 7000
 sample fp16x4_b8 --config fp16x4-b8 --steps 1200
+sample stress_b4 --config stress-b4 --steps 300
+sample fp16x4_stress_b4 --config fp16x4-stress-b4 --steps 400
 head -30 $O/smi_idle.txt
