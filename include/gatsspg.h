@@ -141,7 +141,13 @@ int gatsspg_forward_profiled(const float* packed, const float* desc2d_query, con
  * reference recomputes -- and re-uploads, inference.py:86-90 -- everything per frame.  gnn.layers.0 (GATs),
  * the 3D side of gnn.layers.1 (self), the 3D-side projections / KV sums of gnn.layers.2 (cross) and the leaf logits
  * of the later GATs layers (num_leaf == 8, no linear transform) do not depend on the query frame; gatsspg_prepare_database computes them once, gatsspg_forward_cached skips them.  Results are
- * bit-identical to gatsspg_forward (same kernels, same fixed-order reductions).  The cache does not depend on n1.
+ * bit-identical to gatsspg_forward (same kernels, same fixed-order reductions) WHEN THE CACHE WAS PREPARED UNDER THE SAME `flags` AND
+ * PACKED WEIGHTS as the call that consumes it.  The library does not record them in the cache (the Python wrapper does, and refuses a
+ * mismatch); a C caller that mixes arithmetics gets a well-defined result -- the cached stages in the arithmetic of the prepare call, the
+ * rest in the arithmetic of the forward call -- within the two arithmetics' difference of the plain forward: since round 6 the KV sums of
+ * EVERY arithmetic carry the operand maxima that the fp16 modes' message-operator scale reads (ABI 410), never uninitialised slots
+ * (tests/test_hip_parity.py::test_database_cache_prepared_under_other_flags_is_valid_input_for_the_fp16_modes).  A cache prepared with OTHER
+ * WEIGHTS is simply wrong.  The cache does not depend on n1.
  * ws for prepare: at least gatsspg_workspace_bytes(b, 2, n2, num_leaf). */
 size_t gatsspg_db_cache_bytes(int b, int n2);
 int gatsspg_prepare_database(const float* packed, const float* desc3d_db, const float* desc2d_db, int b, int n2,
