@@ -1133,7 +1133,8 @@ def main():
                                              "_executed_ forms credit only the matrix flops the kernels issue (merge and the attention apply are folded "
                                              "into mlp.0's operator): how busy the fp32 matrix pipe actually is at the nominal 2.4 GHz peak"
                                              + ("" if cfg["precision"] == "fp32" else " (split modes: priced as if on the fp32 pipe; see roofline_floors)"),
-                       "counter_bytes_per_frame": pmc_traffic_per_frame(args.config if not args.shape else "none", frame_launches(cfg["precision"])),
+                       "counter_bytes_per_frame": (lambda t: t and t // bsz)(pmc_traffic_per_frame(args.config if not args.shape else "none", frame_launches(cfg["precision"]))),
+                       "counter_bytes_per_frame_is": "sum over the kernels of a step of (PMC bytes per launch x launches per step) / frames per step, from profiles/pmc_traffic.json",
                        "algorithmic_bytes_per_frame": b_alg(n1, n2, NUM_LEAF) * 1},
             "roofline": {"bound": "hbm" if hbm else "mfma", "kernel": args.kernel + "_kernel", "achieved": round(achieved, 2),
                          "peak": peak, "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(achieved / peak, 4),

@@ -908,8 +908,9 @@ def test_stream_ring_keeps_four_frames_in_flight_with_serial_results():
     frames = [to_dev(synthetic.make_inputs(1, 260 + 8 * i, 700 + 16 * i, 8, seed=90 + i)) for i in range(8)]
     serial = [model.forward_batched(f) for f in frames]
     torch.cuda.synchronize()
-    ring = StreamRing(dev())
-    assert len(ring.streams) == 4
+    ring = StreamRing.shared(dev())          # one ring per process: a second stream set shares hardware queues with the first (runtime.py)
+    assert ring is StreamRing.shared(dev()) and len(ring.streams) == 4
+    assert [s.cuda_stream for s in StreamRing(dev(), 4, streams=ring.streams).streams] == [s.cuda_stream for s in ring.streams]
     for _ in range(3):
         outs = []
         for f in frames:
