@@ -63,9 +63,10 @@ extern "C" {
  *     stays a normal fp16 number for small operands: weights per matrix at pack time (largest entry to [2^13, 2^14): the 2^-23
  *     bound holds down to |w| ~ 2^-24 max|W|), activations by 2^4 (bound holds down to |x| ~ 2^-7, absolute error 2^-29 below;
  *     exact two-term range +-8188, saturating beyond), the message operator M_h of every (segment, head) by a power of two taken from a
- *     RIGOROUS bound of its entries, |M_h| <= (largest row-L1 norm of head h's merge-folded mlp.0 half) * n_source * max K_h * max |V_h|,
- *     with the two data maxima carried by the KV partials (ABI 410; the ABI-400 form, 2^-(ceil(log2 n_source) + 6) of the weight
- *     scale, never looked at the data and could saturate silently on large message weights or a large mean of V).
+ *     RIGOROUS bound of its entries, |M_h| <= (largest row-L1 norm of head h's merge-folded mlp.0 half) * max |V_h| * KS_h, KS_h >= the
+ *     largest key sum max_d sum_m K_h[d][m] (taken as a sum over the 64-column tiles of their largest key sums: one outlier key does not
+ *     move it), both data terms carried by the KV partials (layout of ABI 410; round 5 used n_source * max K_h * max |V_h| there, and the
+ *     ABI-400 form, 2^-(ceil(log2 n_source) + 6) of the weight scale, never looked at the data and could saturate silently).
  *     FP16X3: the three leading products on v_mfma_f32_32x32x16_f16 -- the matrix-pipe time of bf16x3 (BASELINE configs[3] names
  *     fp16; a SINGLE fp16 term fails the parity bar like a single bf16 term does).  FP16X4: all four products, the exact product
  *     of the split operands with fp32 accumulation -- fp32-class results in four MFMAs where bf16x6 needs six.  Measured parity in

@@ -149,7 +149,7 @@ int forward_impl(const float* packed, const float* desc2d_query, const float* de
 
 extern "C" {
 
-int gatsspg_version(void) { return 410; }   // 410: message-operator scale of the fp16 modes from a data bound (KV partials carry operand maxima: packed-weights, workspace and database-cache layouts changed); 400: split-16-bit GEMMs on the LDS-DMA loop, power-of-two operand scales of the fp16 modes (packed-weights and workspace layouts changed)
+int gatsspg_version(void) { return 411; }   // 411: same layouts as 410; the bound data in the KV partials / database cache changed meaning (slots 0..3: per-wave largest key sum of the tile, summed by kv_final; 4..7: max |V|): a cache written by a 410 library must be re-prepared; 410: message-operator scale of the fp16 modes from a data bound (KV partials carry operand maxima: packed-weights, workspace and database-cache layouts changed); 400: split-16-bit GEMMs on the LDS-DMA loop, power-of-two operand scales of the fp16 modes (packed-weights and workspace layouts changed)
 const char* gatsspg_last_error(void) { return g_err; }
 
 size_t gatsspg_packed_weights_bytes(void) { return PACKED_BYTES; }

@@ -12,7 +12,7 @@ constexpr int H = 4;      // heads (GATs_SuperGlue.py:43)
 constexpr int DH = 64;    // channels per head
 constexpr int CP = 128;   // column padding granule: every (frame, side) segment starts on a multiple of CP
 constexpr int BK = 32;    // K tile of every MFMA GEMM
-constexpr int KVMAX = 8;           // operand maxima of a KV partial (fp16 modes): [0..3] max K, [4..7] max |V| of the tile, one slot per wave
+constexpr int KVMAX = 8;           // bound data of a KV partial (message-operator scale of the fp16 modes): [0..3] per-wave largest key sum of the tile, [4..7] max |V| of the tile
 constexpr int KVP = DH * DH + DH + KVMAX;  // one KV partial: the 64x64 KV matrix TRANSPOSED, [d][q] (kv_final owns 4-row d blocks), + 64 ksum + maxima
 constexpr int MOP_LD = 512;        // row stride of the per-segment message operators M_seg [512][256] (two segments share a [512][512] block)
 constexpr int MPL_PLANE = 512 * 256;   // bf16 elements of one split plane of M_seg (slab-major like the weight planes)

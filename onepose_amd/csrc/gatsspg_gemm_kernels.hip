@@ -129,18 +129,23 @@ __global__ __launch_bounds__(T::THREADS, (PREC >= 2 ? 4 : 1)) void qkv_kv_kernel
             opmx = fmaxf(opmx, fabsf(v));
             Tl[row * TS + col] = v;
         }
-    {   // operand maxima of the tile (slots [0..3] max K, [4..7] max |V|, as qkv_kv_sp_kernel writes them): only the fp16 modes' kv_final
-        // reads them, but a KV partial / database cache written in ANY arithmetic must be valid input for it (the C ABI does not tie a
-        // cache to the flags it was prepared with: round-5 advisor, medium) -- never uninitialised workspace
+    {   // bound data of the tile for the fp16 modes' message-operator scale (kv_final_kernel): slots [4..7] = max |V| of the tile, one per wave
+        // that holds V_h rows (the other V slots 0); slots [0..3] = an upper bound of the tile's key sums per K-holding wave.  Written in EVERY
+        // arithmetic: a KV partial / database cache must be valid input for the fp16 modes whatever flags it was prepared under (the C ABI
+        // does not tie a cache to them: round-5 advisor, medium) -- never uninitialised workspace
         static_assert(T::WAVES_MN * T::KS == 8 || (T::WAVES_MN * T::KS == 4 && T::TM == 2), "8 waves: 0..3 hold K_h, 4..7 V_h; 4 waves: 0, 1 K_h, 2, 3 V_h");
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) opmx = fmaxf(opmx, __shfl_xor(opmx, o));
+        // Slots 0..3 here: 64 * (largest K of the wave's quadrant) -- a cheaper, looser member of the same family of bounds (a tile's key sum
+        // over 64 columns is at most 64 max K; the average of two quadrants' bounds is at most the larger): this kernel's arithmetics never
+        // read the slots themselves, they only have to be VALID for an fp16-mode consumer of a cache prepared here, and the tight form (the
+        // per-wave largest key sum, qkv_kv_sp_kernel) measured +2.4 us on this kernel (87 instead of 80 registers: two workgroups per CU).
         if (lane == 0) {
             float* mx = kvpart + ((size_t)ct * H + h) * KVP + DH * DH + DH;
             if constexpr (T::WAVES_MN * T::KS == 8) {
-                mx[wave] = opmx;
+                mx[wave] = wave < 4 ? 64.f * opmx : opmx;
             } else {
-                mx[wave] = wm == 0 ? opmx : 0.f;
+                mx[wave] = wm == 0 ? 64.f * opmx : 0.f;
                 mx[4 + wave] = wm == 0 ? 0.f : opmx;
             }
         }
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
                                                         const float* __restrict__ sc, ColLayout L, int cross, int prec, int abl) {
     __shared__ float4 red[16][64];
     __shared__ float4 kvs[64];   // this block's final KV^T rows: [4 d][16 float4 of q]
-    __shared__ float opmax[2][16];   // fp16 modes: per-wave maxima of K and |V| over the source segment's tiles
+    __shared__ float opsum[16];      // per wave: sum over its tiles of the tile's largest key-sum bound (bound data, slots 0..3)
+    __shared__ float opmax[16];      // per wave: max |V| over the source segment's tiles (slots 4..7)
     constexpr int KVF_ROWS = 512 / KVF_RS;
     if (prec >= 3) fp16_saturate_mode();
     const int tid = threadIdx.x;
@@ -226,12 +232,18 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
     const int tseg = cross ? (seg ^ 1) : seg;
     // fp16 modes: the operator planes of head h hold sM_h * M_h with a power of two sM_h chosen from a RIGOROUS bound of the operator's
     // entries (round-4 advisor: the former 2^-(ceil(log2 n_src) + 6) heuristic never looked at the data and could saturate silently):
-    //     |M_h[r][d]| = |sum_q (W0b Wm)[r][h, q] KV_h[q][d]| <= l1_h * max |KV_h|,   |KV_h[q][d]| = |sum_m V[q][m] K[d][m]| <= n_src * vmax_h * kmax_h
-    // l1_h = largest row-L1 norm of head h's message half (pack time, AttnW::SC[4 + h]); kmax_h / vmax_h = largest K / |V| entry of the
-    // source segment, carried by the KV partials (qkv_kv_sp_kernel) and maximised here by every block -- same loads, same order, same
-    // result in every block of a (segment, head).  sM_h = 2^(14 - e), 2^e > bound: no entry reaches 2^14 (fp16 maximum 65504).  The
-    // bound is loose by the random-sign cancellation of the two sums (typically 2^8 .. 2^13): the largest entries then sit around
-    // 2^1 .. 2^6, where both fp16 terms are still normal numbers (relative error 2^-22); an entry 2^-6 below them keeps 2^-21.
+    //     |M_h[r][d]| = |sum_q (W0b Wm)[r][h, q] KV_h[q][d]| <= l1_h * max |KV_h|,
+    //     |KV_h[q][d]| = |sum_m V[q][m] K[d][m]| <= vmax_h * sum_m K[d][m] = vmax_h * ksum_h[d]       (K = elu + 1 > 0),
+    //     max_d ksum_h[d] <= sum_tiles max_d ksum_tile[d] <= sum_tiles max_w slot_w(tile) =: ksb_h
+    // l1_h = largest row-L1 norm of head h's message half (pack time, AttnW::SC[4 + h]); vmax_h = largest |V| entry of the source segment;
+    // both data terms ride in the KV partials (every projection kernel writes them: slots 0..3 the per-wave largest key sum of the tile,
+    // slots 4..7 max |V|).  Every block of a (segment, head) reduces them with the same loads in the same order: the same scale in all.
+    // (Round 6, advisor: the round-5 form bounded KV by n_src * kmax_h * vmax_h -- one outlier K entry lowered the scale of the whole head;
+    // a sum of per-tile key-sum maxima moves by that entry / n_src, and is 2-4x tighter on ordinary data.)  sM_h = 2^(14 - e), 2^e > bound:
+    // no entry reaches 2^14 (fp16 maximum 65504).  The bound stays loose by the random-sign cancellation of the sums over q and m
+    // (typically 2^7 .. 2^12): the largest entries then sit around 2^2 .. 2^7, where both fp16 terms are normal numbers (2^-22 relative).
+    // kvfin (and through it the database cache) stores the REDUCED slots -- (ksb, 0, 0, 0) and (vmax, 0, 0, 0) -- so that a cached source, read
+    // as a single partial, yields bit for bit the scale of the plain forward (0 + x and max(0, x) are exact).
     // mlp0 folds head h with z_h * zsc_h, zsc_h = (W0 scale) / sM_h: exact.
     const int nsrc = side ? L.n2 : L.n1;
     // operator phase: thread = (row pair rp, q quarter qq); lane qq takes the float4s qq, qq + 4, qq + 8, qq + 12 of the 64 q of a
@@ -260,15 +272,18 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
     const int tb = part * per, te = min(nt, tb + per);
     // operand maxima of the source's tiles (fp16 modes; requested in front of the reduction's loads, consumed behind them)
     constexpr int MAX4 = (DH * DH + DH) / 4;   // float4 index of a partial's maxima: [max K x 4 waves][max |V| x 4 waves]
-    float kmx = 0.f, vmx = 0.f;
-    if (prec >= 3)
-        for (int t = tid; t < nt; t += 1024) {
-            const float4* mp = reinterpret_cast<const float4*>(base + (size_t)t * H * KVP) + MAX4;
-            const float4 a = mp[0], b4 = mp[1];
-            kmx = fmaxf(kmx, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
-            vmx = fmaxf(vmx, fmaxf(fmaxf(b4.x, b4.y), fmaxf(b4.z, b4.w)));
-        }
-    const bool ismax = e4 >= MAX4;   // the maxima elements are combined with max, everything else is summed
+    // the bound data of the source's tiles (requested in front of the reduction's loads, consumed behind them); computed in EVERY arithmetic:
+    // the ksum block stores the reduced slots with kvfin, and a cache prepared in fp32 must serve the fp16 modes
+    float ksb = 0.f, vmx = 0.f;   // ksb: sum over the tiles of the tile's largest key-sum bound (>= max_w sum_tiles slot_w >= max_d ksum[d])
+    const bool need_bound = prec >= 3 || ksum_block;   // (block-uniform) fp32 / bf16 launches: only the block that stores kvfin reduces it
+    if (need_bound)
+    for (int t = tid; t < nt; t += 1024) {
+        const float4* mp = reinterpret_cast<const float4*>(base + (size_t)t * H * KVP) + MAX4;
+        const float4 a = mp[0], b4 = mp[1];
+        ksb += fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w));
+        vmx = fmaxf(vmx, fmaxf(fmaxf(b4.x, b4.y), fmaxf(b4.z, b4.w)));
+    }
+    const bool ismax = e4 >= MAX4;   // (the two bound elements of the partials go through the loop below as well; their result is not used)
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int tt = tb; tt < te; tt += 8) {
         float4 x[8];
@@ -283,23 +298,28 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
             }
     }
     red[part][el] = s;
-    if (prec >= 3) {
+    if (need_bound) {   // fixed-order tree: lanes of a wave by xor-shuffles, then the 16 waves in order (identical in every block of the (segment, head))
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            kmx = fmaxf(kmx, __shfl_xor(kmx, o));
+            ksb += __shfl_xor(ksb, o);
             vmx = fmaxf(vmx, __shfl_xor(vmx, o));
         }
-        if (el == 0) { opmax[0][part] = kmx; opmax[1][part] = vmx; }
+        if (el == 0) { opsum[part] = ksb; opmax[part] = vmx; }
     }
     __syncthreads();
+    if (need_bound) {
+        ksb = opsum[0];
+        vmx = opmax[0];
+#pragma unroll
+        for (int p = 1; p < 16; ++p) {
+            ksb += opsum[p];
+            vmx = fmaxf(vmx, opmax[p]);
+        }
+    }
     float mscale = 1.f, zfold = 1.f;
     if (prec >= 3) {
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            kmx = fmaxf(kmx, opmax[0][p]);
-            vmx = fmaxf(vmx, opmax[1][p]);
-        }
-        const float bound = sc[4 + h] * (float)nsrc * kmx * vmx;
+        (void)nsrc;
+        const float bound = sc[4 + h] * ksb * vmx;
         int e = 0;
         if (bound > 0.f && bound < 3.0e38f) e = min(max(ilogbf(bound) + 1, -100), 100);   // 2^e > bound
         mscale = __builtin_ldexpf(1.f, 14 - e);
@@ -315,6 +335,8 @@ __global__ __launch_bounds__(1024) void kv_final_kernel(const float* __restrict_
         }
         kvs[el] = tot;
         if (db * 64 + el < KVP4 && rs == 0) {
+            if (e4 == MAX4) tot = make_float4(ksb, 0.f, 0.f, 0.f);             // slots 0..3: the tree sum the scale was taken from (max(x, 0, 0, 0) = x)
+            else if (e4 == MAX4 + 1) tot = make_float4(vmx, 0.f, 0.f, 0.f);    // slots 4..7: max |V| (one slot suffices for a single partial)
             *reinterpret_cast<float4*>(kvfin + ((size_t)seg * H + h) * KVP + 4 * e4) = tot;
             if (ksum_block) {
                 if (el < DH / 4) *reinterpret_cast<float4*>(ksumT + ((size_t)tseg * H + h) * DH + 4 * el) = tot;   // ksum of the source

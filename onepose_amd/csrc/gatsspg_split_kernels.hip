@@ -148,18 +148,17 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : 3)) void qkv_kv_sp_kernel
             Tl[row * TS + col] = v;
         }
     {
-        // operand maxima for kv_final's bound of the message operator (|KV_h| <= n_src max K max |V|): slots [0..3] max K, [4..7] max |V|,
-        // one per wave; a wave writes its own slot and zeroes its slot of the other kind.  Written in every arithmetic (only the fp16
-        // modes' kv_final reads them, but a partial / database cache must never carry uninitialised slots: round-5 advisor)
+        // bound data for kv_final's scale of the message operator (|KV_h[q][d]| <= max |V| * ksum[d]): slots [4..7] max |V| per wave here,
+        // slots [0..3] the per-wave largest key sum of the tile (ksum pass below).  Written in every arithmetic (a partial / database cache
+        // must never carry uninitialised slots: round-5 advisor)
         static_assert((T::WAVES == 4 && T::TM == 2) || (T::WAVES == 8 && T::TM == 1), "4 waves: 0, 1 hold K_h, 2, 3 V_h; 8 waves: 0..3 K_h, 4..7 V_h");
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) opmx = fmaxf(opmx, __shfl_xor(opmx, o));
-        if (lane == 0) {
+        if (lane == 0) {   // slots 4..7: max |V| per V-holding wave (0 for the K-holding ones); slots 0..3: the ksum pass below
             float* mx = kvpart + ((size_t)ct * H + h) * KVP + DH * DH + DH;
             if constexpr (T::WAVES == 8) {
-                mx[wave] = opmx;
+                if (wave >= 4) mx[wave] = opmx;
             } else {
-                mx[wave] = wm == 0 ? opmx : 0.f;
                 mx[4 + wave] = wm == 0 ? 0.f : opmx;
             }
         }
@@ -195,6 +194,11 @@ __global__ __launch_bounds__(T::THREADS, (T::F32 ? 4 : 3)) void qkv_kv_sp_kernel
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
             if (qtr == 0) out[DH * DH + d] = s;
+            // slot `wave` of the bound data (kv_final_kernel): the largest of this wave's 16 key sums
+            float m = s;
+#pragma unroll
+            for (int o = 4; o <= 32; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (lane == 0) out[DH * DH + DH + wave] = m;
         }
     }
 }

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.gatsspg_version() >= 410
+    assert lib.gatsspg_version() >= 411
     big = 768 * 256 + 512 * 512 + 256 * 512           # the three big operators of an attention layer
     assert lib.gatsspg_packed_weights_bytes() == (4 * (8 * (big + 768 + 512 + 256 + 8) + 4 * (512 + 256 * 256) + 256 * 256 + 256)   # + 8: fp16 plane scales (4) and the per-head row-L1 norms of the message half (4) per layer
                                                  
@@ -86,7 +86,7 @@ lib.gatsspg_workspace_bytes.restype = c_size_t
 lib.gatsspg_db_cache_bytes.restype = c_size_t
 lib.gatsspg_packed_weights_bytes.restype = c_size_t
 lib.gatsspg_kenc_scratch_bytes.restype = c_size_t
-assert lib.gatsspg_version() >= 410 and lib.gatsspg_packed_weights_bytes() > 0
+assert lib.gatsspg_version() >= 411 and lib.gatsspg_packed_weights_bytes() > 0
 for args in ((1, 1000, 7000, 8), (8, 1000, 7000, 8), (1, 2, 2, 1), (1, 1, 7000, 8), (0, 10, 10, 8), (1, 10, 10, 65), (4096, 100000, 100000, 8)):
     lib.gatsspg_workspace_bytes(*args)
     lib.gatsspg_last_error()

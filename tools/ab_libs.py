@@ -27,7 +27,11 @@ for path in a.libs:
     w = bench.Weights(dev, cfg["precision"])
     base = bench.Runner(dev, w, shared, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], golden_seed=bench.GOLDEN_SEEDS.get(cfg["golden"]))
     shared = base.shared_inputs
-    sets[path] = (w, base, [bench.Runner(dev, w, shared, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], own_stream=True) for _ in range(a.slots)])
+    # both builds drive THE SAME streams: a second stream set created later shares hardware queues with the first and runs the same calls
+    # 8-12 % slower (profiles/r06g_module_overhead_*_streams.txt) -- that would be charged to whichever library is listed second
+    first = next(iter(sets.values()))[2] if sets else None
+    sets[path] = (w, base, [bench.Runner(dev, w, shared, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], own_stream=True,
+                                         stream=first[i].stream if first else None) for i in range(a.slots)])
 K = a.steps
 res = {p: {"lat": [], "thr": [], "par": None} for p in a.libs}
 for rnd in range(a.rounds + 1):
