@@ -1140,7 +1140,8 @@ m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.i
 m = m.to('cuda:0')
 for shape in ((1, 1000, 7000), (2, 300, 900)):
     data = {k: torch.from_numpy(v).to('cuda:0') for k, v in synthetic.make_inputs(shape[0], shape[1], shape[2], 8, seed=11).items()}
-    for knobs in ('', 'FP32_DIRECT=0', 'FP32_DIRECT=1', 'FP32_DIRECT=2'):
+    # ... and (round 6) the quarter-fragment / bias-table register diets of qkv_kv, mlp0 and mlp3 against the two-half fragment loop
+    for knobs in ('', 'FP32_DIRECT=0', 'FP32_DIRECT=1', 'FP32_DIRECT=2', 'MLP0_DIET=0,QKV_DIET=0', 'MLP0_DIET=1,QKV_DIET=1', 'MLP0_DIET=2,QKV_DIET=2', 'MLP3_DIET=1'):
         for k in [k for k in os.environ if k.startswith('GATSSPG_')]:
             del os.environ[k]
         for kv in filter(None, knobs.split(',')):
@@ -1155,7 +1156,8 @@ print('SCHEDULE_PROBE ' + json.dumps(out))
 
 def test_split_loop_schedules_are_bit_identical():
     """The schedules of the LDS-DMA split loop (gemm_split_glds.h: SCHED 0 / 2 / 3 / 4), the direct and the LDS-staged store of the
-    plain tiles, the two- / three-stage rings and the XCD pairing of the 64-column kernels differ in WHEN (or WHERE) an instruction is
+    plain tiles, the two- / three-stage rings, the XCD pairing of the 64-column kernels and (round 6) the register diets of the fp32 GEMMs
+    (quarter fragments, bias table: what launches of more than 64 tiles run by default) differ in WHEN (or WHERE) an instruction is
     issued, never in the order of additions into an accumulator: conf and matches must come out bit for bit the same.  The transposed
     mlp.0 epilogue (GATSSPG_SP_UT=1, round 5) re-associates the InstanceNorm partials: fp32 noise on conf, identical matches.  Runs the tuning build (environment knobs read per launch) in a
     process of its own; skipped when that library is not built (`python -m onepose_amd.build_ext --tuning`)."""
