@@ -655,9 +655,6 @@ __global__ __launch_bounds__(1024) void stat_final_kernel(const float* __restric
 using Mlp3TileTallW8 = GemmTile<128, 64, 4, 2, false>;   // both arithmetics: 128x64 on 8 waves, 252 workgroups (fp32: 21.3 vs 24.6 us, 938 vs 914 frames/s one at a time)
 using Mlp3Tile = GemmTile<64, 64, 2, 2, false>;          // alternative (tuning builds): 64x64 on 4 waves, 504 workgroups
 using Mlp3TileS = GemmTile<64, 64, 2, 2, false, false, 2>;   // fp32, launches that leave CUs empty: 64x64, two K groups of 4 waves
-// (round 6, measured and removed: a 128 x 32 tile on 4 waves = 504 workgroups, two independent workgroups per CU on barriers of their own:
-//  27.7 vs 24.7 us event-timed at the headline shape, 974 vs 1001 frames/s one at a time, 1229 vs 1247 in flight; 500 x 2000 equal; 8 frames per
-//  step 1201 vs 1229 -- half the column width doubles the A traffic per product; profiles/r06k_ab_live_mlp3_n32_*.txt)
 
 // DS: the output tile leaves straight from the accumulators (store_tile_regs; plain 128 x 64 / 64 x 64 tiles, not the K-split one)
 template <class T, int ABL = 0, int PREC = 0, int DS = 0, int QF = 0>
