@@ -694,6 +694,9 @@ CONFIGS = {
     "trained-hard": dict(b=1, n1=1000, n2=7000, precision="fp32", golden="trained_hard", weights="trained",
                          what="trained weights, noisier planted frames (conf of the true pairs 0.002 ... 0.91, the 0.2 threshold cuts through them)"),
 }
+# the per-GPU shares of BASELINE configs[2] / configs[4] that ride the default (headline) line under config.other_baseline_configs
+OTHER_BASELINE_CONFIGS = (("configs[2]", "fp16x4-b8"), ("configs[2] in fp32", "fp32-b8"), ("configs[4]", "stress-b4"),
+                          ("configs[4] on the 16-bit pipe", "fp16x4-stress-b4"))
 GOLDEN_SEEDS = {"head_rand": 1, "head_b8": 3, "stress_rand": 5, "stress_b4": 7, "real_rand": 8, "real_b8": 9}   # make_inputs seeds of tests/golden/make_bench_golden.py
 
 
@@ -797,6 +800,65 @@ def side_arithmetic(device, cfg, precision, shared_inputs, K, W, S, streams=None
             "max_abs_conf_err_vs_reference_golden": par and par["max_abs_conf_err"], "argmax_flips_vs_reference_golden": par and par["argmax_flips"]}
 
 
+def baseline_config_leg(device, name, streams, rank, passes=3, steps=16, dry=False):
+    """One of BASELINE.json's OTHER configs on the driver's own line: the per-GPU share of configs[2] (8 frames of 1000/7000 per step)
+    or configs[4] (4 frames of 1000/20000 per step), run by EVERY rank after the timed region of the headline workload, under the same
+    protocol (exactly `steps` steps between barrier + synchronize pairs, first pass discarded, median of `passes`, max over ranks through
+    one metrics all_gather) -- at --gpus 8 this IS configs[2] / configs[4] (64 / 32 frames per step over 8 GPUs).  Rank 0 adds the parity
+    number against the reference-run golden of that shape.  Reported under config.other_baseline_configs, never as `value`."""
+    cfg = CONFIGS[name]
+    S = len(streams)
+    if dry:     # (bench.py --dry-run: the collective plumbing of the leg on CPU over gloo, stub steps)
+        weights, base, slots = None, None, [DryRunner(cfg["b"]) for _ in range(S)]
+        sync = lambda: None  # noqa: E731
+    else:
+        weights = Weights(device, cfg["precision"])
+        base = Runner(device, weights, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], golden_seed=GOLDEN_SEEDS.get(cfg["golden"]), stream=streams[0])
+        slots = [base] + [Runner(device, weights, base.shared_inputs, b=cfg["b"], n1=cfg["n1"], n2=cfg["n2"], stream=streams[i]) for i in range(1, S)]
+        sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
+
+    def timed_pass():
+        sync()
+        sharding.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            slots[i % S].step(i)
+        sync()
+        sharding.barrier()
+        return time.perf_counter() - t0
+
+    first = timed_pass()
+    reps = [timed_pass() for _ in range(passes)]
+    per_rank = sharding.gather_metrics([steps * cfg["b"], float(np.median(reps))], device=device).cpu()
+    value, seconds = sharding.aggregate_throughput(per_rank)
+    world = per_rank.shape[0]
+    out = None
+    if rank == 0 and dry:
+        out = {"name": name, "frames_per_sec": round(value, 2), "n_gpus": world, "frames_per_step_all_gpus": cfg["b"] * world,
+               "per_rank_frames_per_sec": [round(k / t, 2) for k, t in per_rank.tolist()]}
+    elif rank == 0:
+        par = golden_parity(base, cfg)
+        nterms = {"fp32": 1, "fp16x4": 4, "bf16x6": 6}[cfg["precision"]]
+        fl = roofline_floors(cfg["n1"], cfg["n2"], cfg["precision"])
+        out = {"workload": cfg["what"], "name": name, "frames_per_sec": round(value, 2), "n_gpus": world,
+               "frames_per_step_per_gpu": cfg["b"], "frames_per_step_all_gpus": cfg["b"] * world, "frames_in_flight_per_gpu": S * cfg["b"],
+               "steps": steps, "ms_per_step": round(seconds / steps * 1e3, 4),
+               "timed_pass_seconds": [round(t, 5) for t in reps], "discarded_first_pass_seconds": round(first, 5),
+               "per_rank_frames_per_sec": [round(k / t, 2) for k, t in per_rank.tolist()],
+               "dtype": "f32" if cfg["precision"] == "fp32" else cfg["precision"],
+               "roofline_floors": fl,
+               "end_to_end_frac_of_binding_floor": round(max(fl["mfma_floor_ms_per_frame"], fl["hbm_floor_ms_per_frame"]) * 1e-3 * value / world, 4),
+               "products_per_fp32_product": nterms,
+               "counter_bytes_per_frame": (lambda t: t and t // cfg["b"])(pmc_traffic_per_frame(name, frame_launches(cfg["precision"]))),
+               "algorithmic_bytes_per_frame": b_alg(cfg["n1"], cfg["n2"], NUM_LEAF),
+               "parity_check": par}
+    del slots, base, weights
+    if not dry:
+        torch.cuda.empty_cache()
+    return out
+
+
 def self_launch(args, argv):
     """--gpus N without a torchrun environment: re-exec under torch.distributed.run, one rank per GPU (RCCL)."""
     import socket
@@ -862,7 +924,10 @@ def main():
                     help="load lib*_tuning.so (python -m onepose_amd.build_ext --tuning): GATSSPG_<KNOB> environment knobs select "
                          "alternative tile shapes for A/B runs; the line is labelled and is never a headline number")
     ap.add_argument("--no-side-arithmetics", action="store_true",
-                    help="headline config: skip the extra bf16x6 / bf16x3 passes reported under config.other_gemm_arithmetics")
+                    help="headline config: only the headline workload -- skip the other arithmetics (config.other_gemm_arithmetics) and the other "
+                         "BASELINE configs (config.other_baseline_configs): profiler runs")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="headline config: skip the BASELINE configs[2] / configs[4] per-GPU-share passes reported under config.other_baseline_configs")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: stub steps on CPU over gloo -- tests the --gpus N launcher, barrier, metrics gather and JSON line")
     args = ap.parse_args()
@@ -969,6 +1034,9 @@ def main():
     if args.dry_run:
         per_rank = sharding.gather_metrics([K * cfg["b"], elapsed, dev_key])
         value, seconds = sharding.aggregate_throughput(per_rank)
+        other = None
+        if args.config == "headline" and not args.shape and not args.no_other_configs and not args.no_side_arithmetics:
+            other = {key: baseline_config_leg(None, name, [None] * S, rank, passes=2, steps=4, dry=True) for key, name in OTHER_BASELINE_CONFIGS}
         if rank == 0:
             print(json.dumps({"metric": "query_frames_per_sec", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
                               "steps": K, "warmup": W, "ms_per_step": round(seconds / K * 1e3, 4), "higher_is_better": True,
@@ -977,7 +1045,8 @@ def main():
                                          "frames_per_step_per_gpu": cfg["b"], "frames_per_step_all_gpus": cfg["b"] * world,
                                          "per_rank_frames_per_sec": [round(float(k / t), 2) for k, t, _ in per_rank.tolist()],
                                          "ranks_seen": len({int(d) for _, _, d in per_rank.tolist()}),
-                                         "rank_devices": [int(d) for _, _, d in per_rank.tolist()]}}), flush=True)
+                                         "rank_devices": [int(d) for _, _, d in per_rank.tolist()],
+                                         **({"other_baseline_configs": other} if other else {})}}), flush=True)
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
@@ -1066,6 +1135,13 @@ def main():
     # the one (RCCL) collective: timings + the identity key of the device each rank drives (float64: keys are exact integers)
     per_rank = sharding.gather_metrics([K * runner.b, elapsed, solo if solo is not None else elapsed, dev_key], device=device)
     value, seconds = sharding.aggregate_throughput(per_rank.cpu())
+
+    # BASELINE configs[2] / configs[4] on the same line (every rank: the passes hold barriers; at --gpus 8 they are those configs themselves)
+    other = None
+    if args.config == "headline" and not args.shape and not args.no_other_configs and not args.no_side_arithmetics and not args.tuning_lib:
+        other = {}
+        for key, name in OTHER_BASELINE_CONFIGS:
+            other[key] = baseline_config_leg(device, name, [sl.stream for sl in slots], rank)
 
     if rank == 0:
         n1, n2, bsz = cfg["n1"], cfg["n2"], runner.b
@@ -1166,6 +1242,11 @@ def main():
                            "products per fp32 product (dropped terms <= 2^-24 |ab|), fp32 accumulation: fp32-class arithmetic. "
                            "bf16x3: two planes, three products (~2^-16 relative).  fp16x3: two fp16 terms (2 x 11 significand bits, ~2^-20 relative), "
                            "three fp16 MFMA products; fp16x4: all four products of the same terms (fp32-class)")
+        if other:
+            out["config"]["other_baseline_configs"] = dict(
+                other, note="BASELINE.json's configs[2] (64 frames of 1000/7000 sharded 8 per GPU, 16-bit MFMA) and configs[4] (32 frames of "
+                            "1000/20000 sharded 4 per GPU) as their per-GPU share on THIS run's ranks: with n_gpus = 8 they are those configs; "
+                            "measured after the timed region of the headline workload, never part of value")
         if world == 1 and not args.no_cpu_baseline and args.config == "headline":
             if prev_affinity is not None:      # the CPU leg uses the host's cores, not the launch thread's NUMA node
                 os.sched_setaffinity(0, prev_affinity)

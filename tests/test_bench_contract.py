@@ -47,6 +47,15 @@ def test_default_line_contract():
     assert c["module_forward_frames_per_sec"] > 0.85 * d["value"] and c["module_forward_single_stream_frames_per_sec"] > 0.85 * c["single_stream_frames_per_sec"]
     # both readings of the end-to-end matrix-pipe fraction: algorithmic flops and the flops the kernels execute
     assert 0 < c["end_to_end_executed_f32_mfma_frac"] < c["end_to_end_f32_mfma_frac"] < 1 and c["executed_gflop_per_frame"] < c["algorithmic_gflop_per_frame"]
+    # BASELINE configs[2] / configs[4] (per-GPU shares) ride the same line, each with its parity number against the reference-run golden
+    oc = c["other_baseline_configs"]
+    for key, name, b, n2, max_flips in (("configs[2]", "fp16x4-b8", 8, 7000, 0), ("configs[2] in fp32", "fp32-b8", 8, 7000, 0),
+                                         ("configs[4]", "stress-b4", 4, 20000, 2), ("configs[4] on the 16-bit pipe", "fp16x4-stress-b4", 4, 20000, 2)):
+        o = oc[key]
+        assert o["name"] == name and o["n_gpus"] == 1 and o["frames_per_step_all_gpus"] == b and o["frames_per_sec"] > 100, o
+        pc2 = o["parity_check"]     # (stress_b4: the reference's own top-2 gaps at two arg-maxes are 6.4e-7 / 2.7e-5, tests/test_hip_parity.py)
+        assert pc2["max_abs_conf_err"] < 1e-4 and pc2["argmax_flips"] <= max_flips and pc2["argmax_checked"] == b * (1000 + n2), (key, pc2)
+        assert abs(o["frames_per_sec"] * o["ms_per_step"] * 1e-3 / b - 1) < 1e-2
     # ... and, on trained weights, conf values of O(1) and the thresholded matches (fp32 and fp16x4)
     assert "error" not in d["parity_check_trained_weights"], d["parity_check_trained_weights"]
     for prec, pt in d["parity_check_trained_weights"].items():
@@ -109,6 +118,12 @@ def test_gpus_n_launches_n_ranks_by_itself():
     d = run("--gpus", "2", "--dry-run", "--steps", "10", "--warmup", "1", "--reps", "2", env=env)
     assert d["n_gpus"] == 2 and d["data"] == "dry-run" and len(d["config"]["per_rank_frames_per_sec"]) == 2
     assert d["config"]["ranks_seen"] == 2 and len(set(d["config"]["rank_devices"])) == 2   # two ranks, two distinct "devices" (processes)
+    # the BASELINE configs[2] / configs[4] legs of the default line run on EVERY rank (their passes hold barriers, their rates one all_gather)
+    oc = d["config"]["other_baseline_configs"]
+    assert set(oc) == {"configs[2]", "configs[2] in fp32", "configs[4]", "configs[4] on the 16-bit pipe"}
+    assert oc["configs[2]"]["name"] == "fp16x4-b8" and oc["configs[2]"]["frames_per_step_all_gpus"] == 16 and oc["configs[2]"]["n_gpus"] == 2
+    assert oc["configs[4]"]["name"] == "stress-b4" and oc["configs[4]"]["frames_per_step_all_gpus"] == 8
+    assert all(len(v["per_rank_frames_per_sec"]) == 2 and v["frames_per_sec"] > 0 for v in oc.values())
     bad = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,
                        timeout=120, cwd=ROOT, env=bad)
